@@ -277,12 +277,13 @@ static inline int box_max_extent(const Box& b) {
 static inline V3 box_offset(const Box& b, V3 p) { return divv(sub(p, b.lo), sub(b.hi, b.lo)); }
 static inline V3 box_centroid(const Box& b) { return mul(v3s(0.5f), add(b.lo, b.hi)); }
 
-// orion/AABB.hpp:30-42
+// orion/AABB.hpp:30-42.  As built with -mfma the sum front + bottom + side keeps
+// the first product rounded and fuses the other two (seen in recursiveConstruct).
 static inline float box_area(const Box& b) {
     if (b.lo.x > b.hi.x && b.lo.y > b.hi.y && b.lo.z > b.hi.z) return 0;
     float dX = b.hi.x - b.lo.x, dY = b.hi.y - b.lo.y, dZ = b.hi.z - b.lo.z;
-    float front = dX * dY, bottom = dX * dZ, side = dY * dZ;
-    return 2 * (front + bottom + side);
+    float front = dX * dY;
+    return 2 * fmaf(dY, dZ, fmaf(dX, dZ, front));
 }
 
 // orion/avx/sbvh.cpp:115-235.  strategy: 0 MEDIAN (the live default), 1 MIDDLE, 2 SAH (12 buckets)
@@ -325,7 +326,8 @@ static int32_t build_node(Mesh& m, int strategy, uint32_t begin, uint32_t end) {
             Box b1 = box_empty(); unsigned c1 = 0;
             b0 = box_union(b0, buckets[i].b); c0 += buckets[i].count;
             for (uint32_t j = i + 1; j < NBUCKETS; j++) { b1 = box_union(b1, buckets[j].b); c1 += buckets[j].count; }
-            cost[i] = 1.0f + 1.0f * (c0 * box_area(b0) + c1 * box_area(b1)) / box_area(all);
+            // count0*area0 rounded, count1*area1 fused into the sum (as built, orion/avx/sbvh.cpp:199-200)
+            cost[i] = 1.0f + fmaf((float)c1, box_area(b1), (float)c0 * box_area(b0)) / box_area(all);
         }
         float minCost = cost[0]; unsigned minB = 0;
         for (uint32_t i = 1; i < NBUCKETS - 1; i++) if (cost[i] < minCost) { minCost = cost[i]; minB = i; }

@@ -1,0 +1,852 @@
+// HIP kernels for gfx950 (MI355X) and the C ABI declared in include/orion_hip.h.
+//
+// Pipeline of one render batch (a wavefront path tracer over ray queues in HBM):
+//   generate      one primary ray per (pixel, sample)                 orion/raytracer.cpp:72-80
+//   per bounce:
+//     extend      closest hit of every queued ray                     orion/model.hpp:52-62, orion/avx/sbvh.cpp:36-83
+//     shade       surface + direct light (light-sample rays traced
+//                 in place) + roulette + next ray, survivors
+//                 compacted into the next queue with a wave ballot    orion/raytracer.cpp:116-206
+//   resolve       per-pixel sum of the batch's samples, in sample
+//                 order, into the caller's accumulator                orion/raytracer.cpp:84-86
+// Every kernel is built twice: with the per-lane traversal and with the
+// wave-synchronous (scalar-load) traversal of intersect.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orion_hip.h"
+#include "shading.h"
+
+using namespace orion_dev;
+
+// ===========================================================================
+// Kernels
+// ===========================================================================
+namespace {
+
+constexpr int kBlock = 256;
+
+enum { MODE_LANE = 0, MODE_WAVE = 1 };
+
+template <int MODE, bool ANY>
+__device__ __forceinline__ void traverse(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
+    if (MODE == MODE_WAVE) {
+        traverse_wave<ANY>(S, o, d, h, active);
+    } else {
+        if (active) traverse_lane<ANY>(S, o, d, h);
+    }
+}
+
+__device__ __forceinline__ HitRec miss_rec() { HitRec h; h.t = INFINITY; h.u = 0.0f; h.v = 0.0f; h.gtri = kInvalid; return h; }
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Wave-level queue append: one atomic per wave, slots in lane order.
+__device__ __forceinline__ uint32_t queue_slot(bool push, uint32_t* counter) {
+    const uint64_t m = __ballot(push);
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    uint32_t base = 0;
+    if (cnt) {
+        if (lane_id() == 0) base = atomicAdd(counter, cnt);
+        base = __shfl(base, 0);
+    }
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    return base + rank;
+}
+
+// --- ray-query entry points --------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_closest_api(SceneView S, const float* __restrict__ org, const float* __restrict__ dir,
+                                                        uint32_t n, OrionHit* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < n;
+    V3 o = splat(0.0f), d = splat(1.0f);
+    if (active) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); }
+    HitRec h = miss_rec();
+    traverse<MODE, false>(S, o, d, h, active);
+    if (active) {
+        OrionHit r;
+        r.mesh = kInvalid; r.tri = kInvalid; r.t = h.t; r.u = h.u; r.v = h.v;
+        if (h.gtri != kInvalid) {
+            r.mesh = S.attrs[h.gtri].mesh;
+            r.tri = h.gtri - S.meshes[r.mesh].tri_base;
+        }
+        out[i] = r;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_anyhit_api(SceneView S, const float* __restrict__ org, const float* __restrict__ dir,
+                                                       uint32_t n, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < n;
+    V3 o = splat(0.0f), d = splat(1.0f);
+    if (active) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); }
+    HitRec h = miss_rec();
+    traverse<MODE, true>(S, o, d, h, active);
+    if (active) out[i] = h.gtri != kInvalid ? 1 : 0;
+}
+
+// --- path tracing --------------------------------------------------------------
+struct Queues {
+    float4* o;    // origin.xyz, path id
+    float4* d;    // direction.xyz
+    float4* T;    // throughput.xyz
+};
+
+__device__ __forceinline__ void path_pixel(const FrameParams& F, uint32_t pid, uint32_t& pixel, uint32_t& sample, uint32_t& px, uint32_t& py) {
+    const uint32_t P = F.tile_w * F.tile_h;
+    const uint32_t k = pid / P, p = pid - k * P;
+    py = F.tile_y0 + p / F.tile_w;
+    px = F.tile_x0 + p % F.tile_w;
+    pixel = py * F.width + px;
+    sample = F.spp_begin + k;
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, uint32_t n_paths, Queues q, float4* __restrict__ rad) {
+    const uint32_t pid = blockIdx.x * kBlock + threadIdx.x;
+    if (pid >= n_paths) return;
+    uint32_t pixel, sample, px, py;
+    path_pixel(F, pid, pixel, sample, px, py);
+    // per-sample jitter shared by all pixels (orion/raytracer.cpp:53-63)
+    const Words4 r = philox4x32_10(kPatternPixel, sample, 0u, kBlockPattern, F.seed_lo, F.seed_hi);
+    const float pixelX = 2.0f / (float)F.width, pixelY = 2.0f / (float)F.height;
+    const float jx = pixelX * u01(r.w[0]), jy = pixelY * u01(r.w[1]);
+    const float x = 2 * ((float)px / (float)F.width) - 1;
+    const float y = 2 * ((float)py / (float)F.height) - 1;
+    const float xs = x + jx, ys = -(y + jy);
+    const V3 dir = (ld3(F.front) + ld3(F.right) * xs) + ld3(F.up) * ys;
+    q.o[pid] = make_float4(F.eye[0], F.eye[1], F.eye[2], __uint_as_float(pid));
+    q.d[pid] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+    q.T[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    rad[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues q, uint32_t n, HitRec* __restrict__ hits) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < n;
+    V3 o = splat(0.0f), d = splat(1.0f);
+    if (active) {
+        const float4 a = q.o[i], b = q.d[i];
+        o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
+    }
+    HitRec h = miss_rec();
+    traverse<MODE, false>(S, o, d, h, active);
+    if (active) reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.gtri));
+}
+
+// One bounce of RayTracer::trace after the closest hit is known
+// (orion/raytracer.cpp:116-206).  POINT selects the point-light branch.
+template <int MODE, bool POINT>
+__global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, uint32_t depth, Queues qin, uint32_t n,
+                                                  const HitRec* __restrict__ hits, Queues qout, uint32_t* __restrict__ out_count,
+                                                  float4* __restrict__ rad) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool live = i < n;
+    V3 o = splat(0.0f), d = splat(1.0f), T = splat(0.0f);
+    uint32_t pid = 0;
+    HitRec h = miss_rec();
+    if (live) {
+        const float4 a = qin.o[i], b = qin.d[i], c = qin.T[i];
+        o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); T = mk(c.x, c.y, c.z);
+        pid = __float_as_uint(a.w);
+        const float4 hr = reinterpret_cast<const float4*>(hits)[i];
+        h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
+        live = h.gtri != kInvalid;   // a miss contributes nothing and ends the path (orion/raytracer.cpp:113-114)
+    }
+
+    const float bias = 1e-3f;
+    V3 normal = splat(0.0f), hitPos = splat(0.0f), biased = splat(0.0f), color = splat(0.0f);
+    float tu = 0.0f, tv = 0.0f;
+    uint32_t mesh_id = 0;
+    uint32_t pixel = 0, sample = 0;
+    if (live) {
+        uint32_t px, py;
+        path_pixel(F, pid, pixel, sample, px, py);
+        const Surface sf = surface_at(S, h.gtri, h.u, h.v);
+        mesh_id = sf.mesh; tu = sf.tu; tv = sf.tv;
+        normal = normalize(sf.normal);
+        hitPos = o + d * h.t;
+        biased = hitPos + normal * bias;
+        if (depth == 0) {   // primary ray sees an emissive surface (orion/raytracer.cpp:127-128)
+            const Mesh m = S.meshes[mesh_id];
+            const float dn = dot(normalize(d), -normal);
+            color = (tex_fetch(S, m.tex[kTexEmissive], tu, tv) * m.area) * dn;
+        }
+    }
+
+    bool cont = false;
+    V3 next_d = splat(0.0f), next_T = splat(0.0f);
+
+    if (!POINT) {
+        // Direct light: light_samples points on every emissive mesh (orion/raytracer.cpp:133-159)
+        V3 kd = splat(0.0f);
+        if (live) kd = tex_fetch(S, S.meshes[mesh_id].tex[kTexDiffuse], tu, tv);
+        const float inv_ls = 1.0f / (float)F.light_samples;
+        for (uint32_t e = 0; e < S.n_emissive; e++) {
+            const uint32_t lmesh = S.emissive[e];
+            const Mesh lm = S.meshes[lmesh];
+            V3 contrib = splat(0.0f);
+            for (uint32_t l = 0; l < F.light_samples; l++) {
+                V3 target = splat(0.0f), sd = splat(1.0f);
+                float lbias = 0.0f;
+                if (live) {
+                    const Words4 r = philox4x32_10(pixel, sample, depth, e * F.light_samples + l, F.seed_lo, F.seed_hi);
+                    light_point(S, lm, r, target, lbias);
+                    sd = target - hitPos;
+                }
+                HitRec h2 = miss_rec();
+                traverse<MODE, false>(S, biased, sd, h2, live);
+                if (live && h2.gtri != kInvalid) {
+                    const Surface s2 = surface_at(S, h2.gtri, h2.u, h2.v);
+                    if (s2.mesh == lmesh) {   // the sample is visible iff the closest hit is the light itself
+                        const V3 lcol = tex_fetch(S, lm.tex[kTexEmissive], s2.tu, s2.tv);
+                        const float lint = lbias * lm.area;
+                        contrib = contrib + color_brdf(kd, normal, hitPos, target, lcol, lint, normalize(s2.normal));
+                    }
+                }
+            }
+            color = color + contrib * inv_ls;
+        }
+        if (live) {
+            const float4 r0 = rad[pid];
+            const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
+            rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            if (depth < F.max_depth) {
+                // Russian roulette on max(kd), then a cosine-weighted direction (orion/raytracer.cpp:164-194)
+                const float cc = tpl_max(tpl_max(kd.x, kd.y), kd.z);
+                const Words4 r = philox4x32_10(pixel, sample, depth, kBlockBounce, F.seed_lo, F.seed_hi);
+                if (!(u01(r.w[0]) > cc)) {
+                    const float sin_theta = sqrtf(u01(r.w[1]));
+                    const float cos_theta = sqrtf(1 - sin_theta * sin_theta);
+                    const float psi = u01(r.w[2]) * 2.0f * 3.1415926535f;
+                    V3 tangent = cross(normal, mk(0.0f, 1.0f, 0.0f));
+                    if (dot(tangent, tangent) == 0.0f) tangent = cross(normal, mk(0.0f, 0.0f, 1.0f));
+                    const V3 bitangent = cross(normal, tangent);
+                    const float a = sin_theta * cosf(psi), b = sin_theta * sinf(psi), c = cos_theta;
+                    next_d = (tangent * a + bitangent * b) + normal * c;
+                    next_T = (T * kd) / cc;
+                    cont = true;
+                }
+            }
+        }
+    } else {
+        // Point lights: any hit on the unbounded shadow ray occludes (orion/raytracer.cpp:196-201)
+        V3 ka = splat(0.0f), kd = splat(0.0f), ks = splat(0.0f);
+        float shininess = 0.0f;
+        if (live) {
+            const Mesh m = S.meshes[mesh_id];
+            ka = tex_fetch(S, m.tex[kTexAmbient], tu, tv);
+            kd = tex_fetch(S, m.tex[kTexDiffuse], tu, tv);
+            ks = tex_fetch(S, m.tex[kTexSpecular], tu, tv);
+            shininess = m.shininess;
+        }
+        for (uint32_t li = 0; li < F.n_lights; li++) {
+            const V3 lpos = ld3(F.lights[li].position);
+            V3 sd = splat(1.0f);
+            if (live) sd = lpos - hitPos;
+            HitRec h2 = miss_rec();
+            traverse<MODE, true>(S, biased, sd, h2, live);
+            if (live && h2.gtri == kInvalid)
+                color = color + color_phong(ka, kd, ks, shininess, d, normal, hitPos, lpos, ld3(F.lights[li].color), F.lights[li].intensity);
+        }
+        if (live) {
+            const float4 r0 = rad[pid];
+            const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
+            rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            if (depth < F.max_depth) {   // mirror bounce weighted by the specular texel (orion/raytracer.cpp:203-206)
+                next_d = reflect(d, normal);
+                next_T = T * ks;
+                cont = true;
+            }
+        }
+    }
+
+    const uint32_t slot = queue_slot(cont, out_count);
+    if (cont) {
+        qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
+        qout.d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
+        qout.T[slot] = make_float4(next_T.x, next_T.y, next_T.z, 0.0f);
+    }
+}
+
+// image[i][j] += tracedColor for the batch's samples in ascending order (orion/raytracer.cpp:84)
+__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams F, const float4* __restrict__ rad, float4* __restrict__ accum) {
+    const uint32_t P = F.tile_w * F.tile_h;
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t py = F.tile_y0 + p / F.tile_w, px = F.tile_x0 + p % F.tile_w;
+    float4 acc = accum[(size_t)py * F.width + px];
+    for (uint32_t k = 0; k < F.n_samples; k++) {
+        const float4 c = rad[(size_t)k * P + p];
+        acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
+    }
+    accum[(size_t)py * F.width + px] = acc;
+}
+
+} // namespace
+
+// ===========================================================================
+// Host side
+// ===========================================================================
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(2, std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        // grow with headroom so that repeated calls with slowly growing sizes do not reallocate
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(2, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct EventPair { hipEvent_t a, b; int kernel; uint64_t items; };
+
+} // namespace
+
+struct OrionScene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    SceneView view{};
+    std::vector<void*> owned;         // device allocations of the flattened scene
+    std::vector<uint32_t> mesh_tri_base;
+    uint32_t n_nodes = 0, n_tris = 0;
+    // options
+    int traversal = 0;                // 0 auto, 1 lane, 2 wave
+    uint64_t batch_paths = 16u << 20;
+    // staging + queues
+    DevBuf s_org, s_dir, s_out, s_accum;
+    DevBuf q[6], hits, rad, counter;
+    uint32_t* h_count = nullptr;      // pinned
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> pool;
+    OrionKernelStats stats[ORION_KERNEL_COUNT]{};
+
+    int mode() const {
+        if (traversal == 1) return MODE_LANE;
+        if (traversal == 2) return MODE_WAVE;
+        // The wave-synchronous walk costs the union of the lanes' paths, so it only
+        // pays while the whole tree is about as small as one ray's own path.
+        return n_nodes <= 64 ? MODE_WAVE : MODE_LANE;
+    }
+};
+
+namespace {
+
+struct Profiled {
+    OrionScene* s; int kernel; uint64_t items; EventPair ev{}; bool on;
+    Profiled(OrionScene* s_, int k, uint64_t it) : s(s_), kernel(k), items(it), on(s_->profiling) {
+        if (!on) return;
+        auto take = [&]() {
+            hipEvent_t e;
+            if (!s->pool.empty()) { e = s->pool.back(); s->pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        ev.a = take(); ev.b = take(); ev.kernel = kernel; ev.items = items;
+        (void)hipEventRecord(ev.a, s->stream);
+    }
+    ~Profiled() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, s->stream);
+        s->pending.push_back(ev);
+    }
+};
+
+void drain_profile(OrionScene* s) {
+    for (EventPair& p : s->pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            s->stats[p.kernel].launches++;
+            s->stats[p.kernel].items += p.items;
+            s->stats[p.kernel].ms += ms;
+        }
+        s->pool.push_back(p.a); s->pool.push_back(p.b);
+    }
+    s->pending.clear();
+}
+
+bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice;
+}
+
+template <typename T>
+int upload(OrionScene* s, const std::vector<T>& v, const T** out) {
+    void* d = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    HIP_TRY(hipMalloc(&d, bytes ? bytes : 16));
+    s->owned.push_back(d);
+    if (bytes) HIP_TRY(hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(d);
+    return 0;
+}
+
+inline uint32_t grid_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+
+// Depth-first flattening of one mesh's tree into the threaded layout.
+struct Flattener {
+    const OrionMeshDesc& m;
+    uint32_t slot_base;
+    std::vector<Node>& nodes;
+    std::vector<uint8_t> seen;
+    std::string err;
+
+    // Emits the subtree of `ni`; returns false on malformed input.
+    bool emit(uint32_t ni) {
+        // explicit stack: (node, state) to keep deep trees off the C stack
+        struct Item { uint32_t node; uint32_t out_index; int state; };
+        std::vector<Item> st;
+        st.push_back({ni, 0, 0});
+        while (!st.empty()) {
+            Item it = st.back();
+            st.pop_back();
+            if (it.state == 1) {   // subtree done: the skip link is wherever the array ends now
+                nodes[it.out_index].a = (uint32_t)nodes.size();
+                continue;
+            }
+            if (it.node >= m.n_nodes) { err = "BVH child index out of range"; return false; }
+            if (seen[it.node]) { err = "BVH node reachable twice (not a tree)"; return false; }
+            seen[it.node] = 1;
+            const OrionBvhNode& src = m.nodes[it.node];
+            Node n;
+            std::memcpy(n.lo, src.lo, 12); std::memcpy(n.hi, src.hi, 12);
+            const uint32_t ntri = m.n_indices / 3;
+            if (src.is_leaf) {
+                if (src.begin > src.end || src.end > ntri) { err = "BVH leaf range outside the triangle array"; return false; }
+                n.a = slot_base + src.begin;
+                n.b = kLeafFlag | (src.end - src.begin);
+                nodes.push_back(n);
+            } else {
+                n.a = 0; n.b = 0;
+                const uint32_t self = (uint32_t)nodes.size();
+                nodes.push_back(n);
+                st.push_back({0, self, 1});
+                st.push_back({src.child[1], 0, 0});
+                st.push_back({src.child[0], 0, 0});
+            }
+        }
+        return true;
+    }
+};
+
+int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_out) {
+    Profiled prof(s, ORION_KERNEL_CLOSEST_HIT, n);
+    if (s->mode() == MODE_WAVE)
+        hipLaunchKernelGGL(k_closest_api<MODE_WAVE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
+    else
+        hipLaunchKernelGGL(k_closest_api<MODE_LANE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_anyhit(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, uint8_t* d_out) {
+    Profiled prof(s, ORION_KERNEL_ANY_HIT, n);
+    if (s->mode() == MODE_WAVE)
+        hipLaunchKernelGGL(k_anyhit_api<MODE_WAVE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
+    else
+        hipLaunchKernelGGL(k_anyhit_api<MODE_LANE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Stage n*3 floats of ray data on the device if the caller's array is host memory.
+int stage_in(OrionScene* s, DevBuf& buf, const float* any, uint32_t n, const float** dev) {
+    if (is_device_ptr(any)) { *dev = any; return 0; }
+    if (int rc = buf.reserve((size_t)n * 12)) return rc;
+    HIP_TRY(hipMemcpyAsync(buf.p, any, (size_t)n * 12, hipMemcpyHostToDevice, s->stream));
+    *dev = static_cast<const float*>(buf.p);
+    return 0;
+}
+
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// host-side vector helpers for the camera basis (same formulas as the kernels)
+struct H3 { float x, y, z; };
+inline float hdot(H3 a, H3 b) { float p0 = a.x * b.x, p1 = a.y * b.y, p2 = a.z * b.z; return (p0 + p1) + (p2 + 0.0f); }
+inline H3 hcross(H3 a, H3 b) {
+    return {std::fmaf(-a.z, b.y, a.y * b.z), std::fmaf(-a.x, b.z, a.z * b.x), std::fmaf(-a.y, b.x, a.x * b.y)};
+}
+inline H3 hscale(H3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline H3 hnormalize(H3 a) { return hscale(a, 1.0f / std::sqrt(hdot(a, a))); }
+
+} // namespace
+
+extern "C" {
+
+const char* orion_hip_last_error(void) { return g_error.c_str(); }
+
+int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
+                           const OrionMaterialDesc* materials, uint32_t n_materials,
+                           const OrionTextureDesc* textures, uint32_t n_textures,
+                           int device, OrionScene** out) {
+    if (!out) return fail(1, "scene_create: out is null");
+    *out = nullptr;
+    if (n_meshes && !meshes) return fail(1, "scene_create: meshes is null");
+    if (n_materials && !materials) return fail(1, "scene_create: materials is null");
+    if (n_textures && !textures) return fail(1, "scene_create: textures is null");
+
+    // ---- validate and flatten on the host -------------------------------------
+    std::vector<Node> nodes;
+    std::vector<Tri> tris;
+    std::vector<TriAttr> attrs;
+    std::vector<uint32_t> slot_of;
+    std::vector<Mesh> dmeshes(n_meshes);
+    std::vector<uint32_t> emissive;
+
+    for (uint32_t t = 0; t < n_textures; t++) {
+        const OrionTextureDesc& td = textures[t];
+        if (td.width == 0 || td.height == 0 || !td.texels) return fail(1, "scene_create: texture " + std::to_string(t) + " is empty");
+        if (td.format > ORION_TEX_GRAY_U8) return fail(1, "scene_create: texture " + std::to_string(t) + " has an unknown format");
+        if ((uint64_t)td.width * td.height > 0x7FFFFFFFull / 4) return fail(1, "scene_create: texture " + std::to_string(t) + " is too large");
+    }
+    for (uint32_t k = 0; k < n_materials; k++) {
+        const OrionMaterialDesc& md = materials[k];
+        const uint32_t ids[4] = {md.tex_ambient, md.tex_diffuse, md.tex_specular, md.tex_emissive};
+        for (uint32_t id : ids)
+            if (id >= n_textures) return fail(1, "scene_create: material " + std::to_string(k) + " names texture " + std::to_string(id) + " of " + std::to_string(n_textures));
+    }
+
+    uint32_t tri_base = 0;
+    for (uint32_t mi = 0; mi < n_meshes; mi++) {
+        const OrionMeshDesc& m = meshes[mi];
+        const std::string where = "scene_create: mesh " + std::to_string(mi) + ": ";
+        if (m.n_indices % 3) return fail(1, where + "index count is not a multiple of 3");
+        if (m.material >= n_materials) return fail(1, where + "material index out of range");
+        const uint32_t ntri = m.n_indices / 3;
+        if ((ntri && (!m.vertices || !m.indices || !m.tri_order)) || (m.n_nodes && !m.nodes)) return fail(1, where + "null array");
+        if ((uint64_t)tri_base + ntri >= kLeafFlag) return fail(1, where + "too many triangles");
+        for (uint32_t i = 0; i < m.n_indices; i++)
+            if (m.indices[i] >= m.n_vertices) return fail(1, where + "vertex index out of range");
+        std::vector<uint8_t> used(ntri, 0);
+        for (uint32_t i = 0; i < ntri; i++) {
+            if (m.tri_order[i] >= ntri || used[m.tri_order[i]]) return fail(1, where + "tri_order is not a permutation");
+            used[m.tri_order[i]] = 1;
+        }
+
+        const uint32_t slot_base = (uint32_t)tris.size();
+        if (m.n_nodes) {
+            Flattener fl{m, slot_base, nodes, std::vector<uint8_t>(m.n_nodes, 0), std::string()};
+            if (!fl.emit(0)) return fail(1, where + fl.err);
+        }
+        // triangle slots in tri_order (= visit order inside the mesh)
+        const OrionMaterialDesc& md = materials[m.material];
+        float area = 0.0f;
+        slot_of.resize(tri_base + ntri);
+        for (uint32_t i = 0; i < ntri; i++) {
+            const uint32_t o = m.tri_order[i];
+            const float* p0 = m.vertices + 8ull * m.indices[3 * o];
+            const float* p1 = m.vertices + 8ull * m.indices[3 * o + 1];
+            const float* p2 = m.vertices + 8ull * m.indices[3 * o + 2];
+            Tri t{};
+            for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; }
+            t.gtri = tri_base + o;
+            slot_of[tri_base + o] = (uint32_t)tris.size();
+            tris.push_back(t);
+        }
+        attrs.resize(tri_base + ntri);
+        for (uint32_t o = 0; o < ntri; o++) {   // original order: attributes and the area sum
+            const float* p0 = m.vertices + 8ull * m.indices[3 * o];
+            const float* p1 = m.vertices + 8ull * m.indices[3 * o + 1];
+            const float* p2 = m.vertices + 8ull * m.indices[3 * o + 2];
+            TriAttr& a = attrs[tri_base + o];
+            for (int c = 0; c < 3; c++) { a.n0[c] = p0[3 + c]; a.n1[c] = p1[3 + c]; a.n2[c] = p2[3 + c]; }
+            a.uv0x = p0[6]; a.uv0y = p0[7]; a.uv1x = p1[6]; a.uv1y = p1[7]; a.uv2x = p2[6]; a.uv2y = p2[7];
+            a.mesh = mi;
+            H3 e1 = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, e2 = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+            area += std::fabs(hdot(e1, e2)) * 0.5f;   // orion/geometry.hpp:155-157, orion/mesh.hpp:197-208
+        }
+        Mesh& dm = dmeshes[mi];
+        dm.tri_base = tri_base; dm.n_tri = ntri;
+        dm.tex[0] = md.tex_ambient; dm.tex[1] = md.tex_diffuse; dm.tex[2] = md.tex_specular; dm.tex[3] = md.tex_emissive;
+        dm.shininess = md.shininess; dm.area = area;
+        const bool is_emissive = md.emissive_color[0] != 0.0f || md.emissive_color[1] != 0.0f || md.emissive_color[2] != 0.0f;
+        if (is_emissive && ntri) emissive.push_back(mi);
+        tri_base += ntri;
+    }
+
+    std::vector<Texture> dtex(n_textures);
+    std::vector<float> texf;
+    std::vector<uint8_t> texb;
+    for (uint32_t t = 0; t < n_textures; t++) {
+        const OrionTextureDesc& td = textures[t];
+        const size_t px = (size_t)td.width * td.height;
+        dtex[t].width = td.width; dtex[t].height = td.height; dtex[t].format = td.format;
+        if (td.format == ORION_TEX_RGB_F32) {
+            dtex[t].offset = (uint32_t)texf.size();
+            const float* src = static_cast<const float*>(td.texels);
+            texf.insert(texf.end(), src, src + 3 * px);
+        } else {
+            const size_t bpp = td.format == ORION_TEX_RGB_U8 ? 3 : (td.format == ORION_TEX_RGBA_U8 ? 4 : 1);
+            dtex[t].offset = (uint32_t)texb.size();
+            const uint8_t* src = static_cast<const uint8_t*>(td.texels);
+            texb.insert(texb.end(), src, src + bpp * px);
+        }
+    }
+
+    // ---- upload ----------------------------------------------------------------
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return fail(2, "no HIP device"); }
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(2, "cannot select HIP device " + std::to_string(device));
+    OrionScene* s = new OrionScene;
+    s->device = device;
+    auto bail = [&](int rc) { orion_hip_scene_destroy(s); return rc; };
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { s->stream = nullptr; return bail(fail(2, "hipStreamCreate failed")); }
+    if (hipHostMalloc((void**)&s->h_count, 64, hipHostMallocDefault) != hipSuccess) { s->h_count = nullptr; return bail(fail(2, "hipHostMalloc failed")); }
+    SceneView& v = s->view;
+    int rc = 0;
+    if ((rc = upload(s, nodes, &v.nodes))) return bail(rc);
+    if ((rc = upload(s, tris, &v.tris))) return bail(rc);
+    if ((rc = upload(s, attrs, &v.attrs))) return bail(rc);
+    if ((rc = upload(s, slot_of, &v.slot_of))) return bail(rc);
+    if ((rc = upload(s, dmeshes, &v.meshes))) return bail(rc);
+    if ((rc = upload(s, dtex, &v.textures))) return bail(rc);
+    if ((rc = upload(s, texf, &v.texels_f32))) return bail(rc);
+    if ((rc = upload(s, texb, &v.texels_u8))) return bail(rc);
+    if ((rc = upload(s, emissive, &v.emissive))) return bail(rc);
+    v.n_nodes = (uint32_t)nodes.size(); v.n_tris = (uint32_t)tris.size();
+    v.n_meshes = n_meshes; v.n_emissive = (uint32_t)emissive.size();
+    s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
+    for (const Mesh& dm : dmeshes) s->mesh_tri_base.push_back(dm.tri_base);
+    *out = s;
+    return 0;
+}
+
+int orion_hip_scene_destroy(OrionScene* s) {
+    if (!s) return 0;
+    DeviceGuard guard(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    drain_profile(s);
+    for (hipEvent_t e : s->pool) (void)hipEventDestroy(e);
+    for (void* p : s->owned) (void)hipFree(p);
+    s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release();
+    for (DevBuf& b : s->q) b.release();
+    s->hits.release(); s->rad.release(); s->counter.release();
+    if (s->h_count) (void)hipHostFree(s->h_count);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return 0;
+}
+
+int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
+    if (!s || !name) return fail(1, "set_option: null argument");
+    if (!std::strcmp(name, "traversal")) {
+        if (value < 0 || value > 2) return fail(1, "set_option: traversal must be 0, 1 or 2");
+        s->traversal = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "batch_paths")) {
+        if (value < 1 || value > (int64_t)1 << 30) return fail(1, "set_option: batch_paths out of range");
+        s->batch_paths = (uint64_t)value;
+        return 0;
+    }
+    return fail(1, std::string("set_option: unknown option '") + name + "'");
+}
+
+int orion_hip_closest_hit(OrionScene* s, const float* org_any, const float* dir_any, uint32_t n, OrionHit* out_any) {
+    if (!s) return fail(1, "closest_hit: scene is null");
+    if (n == 0) return 0;
+    if (!org_any || !dir_any || !out_any) return fail(1, "closest_hit: null array");
+    DeviceGuard guard(s->device);
+    const float *d_org, *d_dir;
+    if (int rc = stage_in(s, s->s_org, org_any, n, &d_org)) return rc;
+    if (int rc = stage_in(s, s->s_dir, dir_any, n, &d_dir)) return rc;
+    const bool out_dev = is_device_ptr(out_any);
+    OrionHit* d_out = out_any;
+    if (!out_dev) {
+        if (int rc = s->s_out.reserve((size_t)n * sizeof(OrionHit))) return rc;
+        d_out = static_cast<OrionHit*>(s->s_out.p);
+    }
+    if (int rc = launch_closest(s, d_org, d_dir, n, d_out)) return rc;
+    if (!out_dev) HIP_TRY(hipMemcpyAsync(out_any, d_out, (size_t)n * sizeof(OrionHit), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int orion_hip_any_hit(OrionScene* s, const float* org_any, const float* dir_any, uint32_t n, uint8_t* occluded_any) {
+    if (!s) return fail(1, "any_hit: scene is null");
+    if (n == 0) return 0;
+    if (!org_any || !dir_any || !occluded_any) return fail(1, "any_hit: null array");
+    DeviceGuard guard(s->device);
+    const float *d_org, *d_dir;
+    if (int rc = stage_in(s, s->s_org, org_any, n, &d_org)) return rc;
+    if (int rc = stage_in(s, s->s_dir, dir_any, n, &d_dir)) return rc;
+    const bool out_dev = is_device_ptr(occluded_any);
+    uint8_t* d_out = occluded_any;
+    if (!out_dev) {
+        if (int rc = s->s_out.reserve(n)) return rc;
+        d_out = static_cast<uint8_t*>(s->s_out.p);
+    }
+    if (int rc = launch_anyhit(s, d_org, d_dir, n, d_out)) return rc;
+    if (!out_dev) HIP_TRY(hipMemcpyAsync(occluded_any, d_out, n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderParams* p, float* accum_any) {
+    if (!s || !cam || !p || !accum_any) return fail(1, "render: null argument");
+    if (p->width == 0 || p->height == 0) return fail(1, "render: empty image");
+    if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(1, "render: image too large");
+    if (p->spp_end < p->spp_begin) return fail(1, "render: spp_end < spp_begin");
+    if (p->n_lights > (uint32_t)kMaxLights) return fail(1, "render: at most " + std::to_string(kMaxLights) + " point lights");
+    if (p->n_lights && !p->lights) return fail(1, "render: lights is null");
+    if (p->n_lights == 0 && p->light_samples == 0 && s->view.n_emissive) return fail(1, "render: light_samples must be >= 1");
+    uint32_t x0 = p->tile_x0, y0 = p->tile_y0, x1 = p->tile_x1, y1 = p->tile_y1;
+    if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) { x1 = p->width; y1 = p->height; }
+    if (x1 > p->width || y1 > p->height || x0 >= x1 || y0 >= y1) return fail(1, "render: tile rectangle outside the image");
+    if (p->spp_end == p->spp_begin) return 0;
+    DeviceGuard guard(s->device);
+
+    FrameParams F{};
+    std::memcpy(F.eye, cam->eye, 12); std::memcpy(F.front, cam->front, 12);
+    std::memcpy(F.right, cam->right, 12); std::memcpy(F.up, cam->up, 12);
+    F.width = p->width; F.height = p->height;
+    F.tile_x0 = x0; F.tile_y0 = y0; F.tile_w = x1 - x0; F.tile_h = y1 - y0;
+    F.light_samples = p->light_samples; F.max_depth = p->max_depth;
+    F.seed_lo = (uint32_t)p->seed; F.seed_hi = (uint32_t)(p->seed >> 32);
+    F.n_lights = p->n_lights;
+    for (uint32_t i = 0; i < p->n_lights; i++) std::memcpy(&F.lights[i], &p->lights[i], sizeof(Light));
+    const bool point = p->n_lights > 0;
+
+    const uint64_t P = (uint64_t)F.tile_w * F.tile_h;
+    uint64_t per_batch = s->batch_paths / P;
+    if (per_batch < 1) per_batch = 1;
+    const uint64_t max_paths = P * per_batch;
+    if (max_paths >= 0xFFFFFFFFull) return fail(1, "render: tile has too many pixels for one batch");
+
+    const size_t img_bytes = (size_t)p->width * p->height * 16;
+    const bool accum_dev = is_device_ptr(accum_any);
+    float4* d_accum = reinterpret_cast<float4*>(accum_any);
+    if (!accum_dev) {
+        if (int rc = s->s_accum.reserve(img_bytes)) return rc;
+        d_accum = static_cast<float4*>(s->s_accum.p);
+        HIP_TRY(hipMemcpyAsync(d_accum, accum_any, img_bytes, hipMemcpyHostToDevice, s->stream));
+    }
+    for (DevBuf& b : s->q) if (int rc = b.reserve(max_paths * 16)) return rc;
+    if (int rc = s->hits.reserve(max_paths * 16)) return rc;
+    if (int rc = s->rad.reserve(max_paths * 16)) return rc;
+    if (int rc = s->counter.reserve(64)) return rc;
+    uint32_t* d_count = static_cast<uint32_t*>(s->counter.p);
+    Queues qa{static_cast<float4*>(s->q[0].p), static_cast<float4*>(s->q[1].p), static_cast<float4*>(s->q[2].p)};
+    Queues qb{static_cast<float4*>(s->q[3].p), static_cast<float4*>(s->q[4].p), static_cast<float4*>(s->q[5].p)};
+    HitRec* d_hits = static_cast<HitRec*>(s->hits.p);
+    float4* d_rad = static_cast<float4*>(s->rad.p);
+    const int mode = s->mode();
+
+    for (uint64_t sb = p->spp_begin; sb < p->spp_end; sb += per_batch) {
+        const uint32_t ns = (uint32_t)((p->spp_end - sb < per_batch) ? (p->spp_end - sb) : per_batch);
+        F.spp_begin = (uint32_t)sb; F.n_samples = ns;
+        uint32_t n = (uint32_t)(P * ns);
+        {
+            Profiled prof(s, ORION_KERNEL_GENERATE, n);
+            hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, F, n, qa, d_rad);
+        }
+        Queues qin = qa, qout = qb;
+        for (uint32_t depth = 0; n > 0 && depth <= p->max_depth; depth++) {
+            {
+                Profiled prof(s, ORION_KERNEL_CLOSEST_HIT, n);
+                if (mode == MODE_WAVE) hipLaunchKernelGGL(k_extend<MODE_WAVE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, qin, n, d_hits);
+                else hipLaunchKernelGGL(k_extend<MODE_LANE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, qin, n, d_hits);
+            }
+            HIP_TRY(hipMemsetAsync(d_count, 0, 4, s->stream));
+            {
+                Profiled prof(s, ORION_KERNEL_SHADE, n);
+                const dim3 g(grid_for(n)), b(kBlock);
+                if (mode == MODE_WAVE) {
+                    if (point) hipLaunchKernelGGL((k_shade<MODE_WAVE, true>), g, b, 0, s->stream, s->view, F, depth, qin, n, d_hits, qout, d_count, d_rad);
+                    else hipLaunchKernelGGL((k_shade<MODE_WAVE, false>), g, b, 0, s->stream, s->view, F, depth, qin, n, d_hits, qout, d_count, d_rad);
+                } else {
+                    if (point) hipLaunchKernelGGL((k_shade<MODE_LANE, true>), g, b, 0, s->stream, s->view, F, depth, qin, n, d_hits, qout, d_count, d_rad);
+                    else hipLaunchKernelGGL((k_shade<MODE_LANE, false>), g, b, 0, s->stream, s->view, F, depth, qin, n, d_hits, qout, d_count, d_rad);
+                }
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(s->h_count, d_count, 4, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            n = *s->h_count;
+            Queues t = qin; qin = qout; qout = t;
+        }
+        {
+            Profiled prof(s, ORION_KERNEL_RESOLVE, P);
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(P)), dim3(kBlock), 0, s->stream, F, d_rad, d_accum);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (!accum_dev) HIP_TRY(hipMemcpyAsync(accum_any, d_accum, img_bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int orion_hip_camera_vectors(const float eye[3], const float look_at[3], const float up[3],
+                             float y_view, float aspect_ratio, OrionCamera* out) {
+    if (!eye || !look_at || !up || !out) return fail(1, "camera_vectors: null argument");
+    H3 vUp = {up[0], up[1], up[2]};
+    H3 vFront = {look_at[0] - eye[0], look_at[1] - eye[1], look_at[2] - eye[2]};
+    // Gram-Schmidt: up -= (front.up / front.front) * front  (orion/math.hpp:313-317)
+    const float k = hdot(vFront, vUp) / hdot(vFront, vFront);
+    const H3 proj = hscale(vFront, k);
+    vUp = {vUp.x - proj.x, vUp.y - proj.y, vUp.z - proj.z};
+    vUp = hnormalize(vUp);
+    vFront = hnormalize(vFront);
+    H3 vRight = hcross(vFront, vUp);
+    vUp = hscale(hscale(vUp, y_view), 0.5f);
+    vRight = hscale(hscale(hscale(vRight, y_view), aspect_ratio), 0.5f);
+    std::memcpy(out->eye, eye, 12);
+    out->front[0] = vFront.x; out->front[1] = vFront.y; out->front[2] = vFront.z;
+    out->right[0] = vRight.x; out->right[1] = vRight.y; out->right[2] = vRight.z;
+    out->up[0] = vUp.x; out->up[1] = vUp.y; out->up[2] = vUp.z;
+    return 0;
+}
+
+int orion_hip_profile_enable(OrionScene* s, int enable) {
+    if (!s) return fail(1, "profile_enable: scene is null");
+    DeviceGuard guard(s->device);
+    drain_profile(s);
+    std::memset(s->stats, 0, sizeof s->stats);
+    s->profiling = enable != 0;
+    return 0;
+}
+
+int orion_hip_profile_read(OrionScene* s, OrionKernelStats* stats) {
+    if (!s || !stats) return fail(1, "profile_read: null argument");
+    DeviceGuard guard(s->device);
+    drain_profile(s);
+    std::memcpy(stats, s->stats, sizeof s->stats);
+    return 0;
+}
+
+} // extern "C"

@@ -28,6 +28,7 @@ RtcData parse_rtc(const std::string& path) {
     std::ifstream file(path);
     if (!file) {
         std::printf("Error opening file %s\n", path.c_str());
+        std::fflush(stdout);
         return rtc;
     }
     // Payload lines are positional: 1 obj, 2 texture, 3 depth, 4 resolution,
@@ -57,6 +58,7 @@ RtcData parse_rtc(const std::string& path) {
             in >> tag;
             if (tag != 'L' && tag != 'l') {
                 std::printf("Invalid character '%c' in line %d `%s`\n", tag, field + skipped, line.c_str());
+                std::fflush(stdout);
                 break;
             }
             Light l{};

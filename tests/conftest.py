@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ASSETS = os.path.join(ROOT, "tests", "golden", "assets")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+SCENES = {
+    "cornell": "cornell-box/cornell-box.obj",
+    "view_test": "view_test.obj",
+    "hindu": "hindu/hindu.obj",
+    "nanosuit": "nanosuit2/nanosuit2.obj",
+}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def scene_path(name: str) -> str:
+    return os.path.join(ASSETS, SCENES[name])
+
+
+_models = {}
+
+
+def load_model(name: str):
+    """host.Model of a named test scene ('soup' is the synthetic triangle soup)."""
+    from orion_amd import host
+    if name not in _models:
+        if name == "soup":
+            import raygen
+            v, i = raygen.triangle_soup()
+            _models[name] = host.model_from_arrays(v, i)
+        else:
+            _models[name] = host.load_model(scene_path(name))
+    return _models[name]
+
+
+@pytest.fixture(scope="session")
+def models():
+    return load_model

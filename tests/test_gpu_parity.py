@@ -1,0 +1,259 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's golden vectors.
+Integer outputs (mesh, triangle, occlusion) must be identical; t, u, v must be BIT-identical --
+stricter than the 1e-5 relative bar -- because the kernels use the reference's own operation order.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import conftest
+import raygen
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["cornell", "view_test", "hindu", "nanosuit", "soup"]
+BATCHES = ["primary", "bounce", "shadow", "box", "edge"]
+MODES = [(1, "lane"), (2, "wave")]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    from orion_amd import api
+    api.lib()   # raises if the HIP library is missing -- there is no fallback
+    return api
+
+
+_scenes = {}
+
+
+def scene_for(api, name):
+    if name not in _scenes:
+        _scenes[name] = api.Scene(conftest.load_model(name), device=0)
+    return _scenes[name]
+
+
+def oracle_for(name):
+    from oracle import bindings as ob
+    return ob.OracleScene(conftest.load_model(name))
+
+
+def hits_to_arrays(h):
+    return np.stack([h["mesh"], h["tri"]], 1), np.stack([h["t"], h["u"], h["v"]], 1)
+
+
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("mode,tag", MODES)
+def test_closest_hit_golden(gpu, name, mode, tag):
+    if tag == "wave" and name in ("nanosuit", "soup"):
+        batches = ["primary"]   # the wave-synchronous walk is not meant for big trees; one batch proves equality
+    else:
+        batches = BATCHES
+    g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
+    sc = scene_for(gpu, name)
+    sc.set_option("traversal", mode)
+    for b in batches:
+        ids, tuv = hits_to_arrays(sc.closest_hit(g[f"{b}_org"], g[f"{b}_dir"]))
+        assert np.array_equal(ids, g[f"{b}_ids"]), f"{name}/{b}/{tag}: ids"
+        assert np.array_equal(bits(tuv), bits(g[f"{b}_tuv"])), f"{name}/{b}/{tag}: t,u,v bits"
+    sc.set_option("traversal", 0)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_any_hit_golden(gpu, name):
+    g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
+    sc = scene_for(gpu, name)
+    for mode, tag in MODES:
+        if tag == "wave" and name in ("nanosuit", "soup"):
+            continue
+        sc.set_option("traversal", mode)
+        for b in BATCHES:
+            occ = sc.any_hit(g[f"{b}_org"], g[f"{b}_dir"])
+            assert np.array_equal(occ.astype(bool), g[f"{b}_ids"][:, 0] != gpu.INVALID), f"{name}/{b}/{tag}"
+    sc.set_option("traversal", 0)
+
+
+@pytest.mark.parametrize("name,n", [("cornell", 1 << 20), ("soup", 1 << 18), ("nanosuit", 1 << 18)])
+def test_closest_hit_vs_oracle_large(gpu, name, n):
+    model = conftest.load_model(name)
+    sc = scene_for(gpu, name)
+    orc = oracle_for(name)
+    o, d = raygen.box_rays(model, n, seed=21)
+    ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+    oid, otuv = orc.closest_hit(o, d, threads=8)
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(bits(tuv), bits(otuv))
+    occ = sc.any_hit(o, d)
+    assert np.array_equal(occ.astype(bool), oid[:, 0] != gpu.INVALID)
+
+
+def test_device_pointers_and_empty_batches(gpu):
+    import torch
+    model = conftest.load_model("cornell")
+    sc = scene_for(gpu, "cornell")
+    o, d = raygen.box_rays(model, 5000, seed=3)   # ragged: not a multiple of the block size
+    want = sc.closest_hit(o, d)
+    to, td = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    got = sc.closest_hit(to, td).cpu().numpy().view(gpu.HIT_DTYPE).reshape(-1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    occ = sc.any_hit(to, td).cpu().numpy()
+    assert np.array_equal(occ, sc.any_hit(o, d))
+    assert len(sc.closest_hit(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))) == 0
+    one = sc.closest_hit(o[:1], d[:1])
+    assert np.array_equal(one.view(np.uint32), want[:1].view(np.uint32))
+
+
+def test_scene_validation(gpu):
+    import copy
+    model = copy.deepcopy(conftest.load_model("cornell"))
+    model.meshes[5].tri_order = model.meshes[5].tri_order.copy()
+    model.meshes[5].tri_order[0] = model.meshes[5].tri_order[1]
+    with pytest.raises(gpu.OrionError, match="permutation"):
+        gpu.Scene(model, device=0)
+    model = copy.deepcopy(conftest.load_model("cornell"))
+    model.meshes[5].nodes = model.meshes[5].nodes.copy()
+    model.meshes[5].nodes["child"][0] = [0, 0]
+    with pytest.raises(gpu.OrionError, match="tree"):
+        gpu.Scene(model, device=0)
+    # a scene with no triangles at all renders black and misses everything
+    from orion_amd import host
+    empty = host.Model([], [host.Material()])
+    sc = gpu.Scene(empty, device=0)
+    h = sc.closest_hit(np.zeros((3, 3), np.float32), np.ones((3, 3), np.float32))
+    assert (h["mesh"] == gpu.INVALID).all() and np.isinf(h["t"]).all()
+    sc.close()
+
+
+def psnr(a, b):
+    peak = float(np.abs(b).max())
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 999.0 if mse == 0 else 10 * np.log10(peak * peak / mse)
+
+
+CORNELL_CAM = ([-0.10141, 1, 3.00498], [-0.10141, 1, 2.00498], [0, 1, 0], 1.0)
+
+
+@pytest.mark.parametrize("mode,tag", MODES)
+def test_render_brdf_matches_oracle(gpu, mode, tag):
+    """Cornell box, BRDF path tracer (no point lights): same counter-RNG streams on both sides, so the
+    images agree far inside the 40 dB bar; only libm-level sinf/cosf differences remain."""
+    from oracle import bindings as ob
+    sc = scene_for(gpu, "cornell")
+    sc.set_option("traversal", mode)
+    orc = oracle_for("cornell")
+    W, H, spp, L, depth = 96, 64, 8, 2, 12
+    eye, look, up, yv = CORNELL_CAM
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    assert np.array_equal(bits(cam), bits(ob.camera_vectors(eye, look, up, yv, W / H)))
+    img = sc.render(cam, W, H, 0, spp, L, depth, seed=5)
+    ref = orc.render(cam, W, H, 0, spp, L, depth, seed=5, accum_mode=1)
+    assert np.array_equal(img[:, :, 3], ref[:, :, 3]) and (img[:, :, 3] == spp).all()
+    assert np.isfinite(img).all()
+    p = psnr(img[:, :, :3], ref[:, :, :3])
+    assert p > 60.0, f"PSNR {p:.1f} dB"
+    rel = np.abs(img[:, :, :3] - ref[:, :, :3]) / (np.abs(ref[:, :, :3]) + 1e-3)
+    assert np.quantile(rel, 0.99) < 1e-4
+    # the reference's own nesting of the radiance sum differs from the iterative order by rounding only
+    rec = orc.render(cam, W, H, 0, spp, L, depth, seed=5, accum_mode=0)
+    assert psnr(img[:, :, :3], rec[:, :, :3]) > 60.0
+    sc.set_option("traversal", 0)
+
+
+@pytest.mark.parametrize("mode,tag", MODES)
+def test_render_point_light_matches_oracle(gpu, mode, tag):
+    """configs[0]: Cornell box with one point light, Phong + mirror recursion to depth 8."""
+    sc = scene_for(gpu, "cornell")
+    sc.set_option("traversal", mode)
+    orc = oracle_for("cornell")
+    W = H = 64
+    eye, look, up, yv = CORNELL_CAM
+    cam = gpu.camera_vectors(eye, look, up, yv, 1.0)
+    lights = np.array([[0, 1.5, 1.0, 100 / 255, 100 / 255, 100 / 255, 32]], np.float32)
+    img = sc.render(cam, W, H, 0, 4, 1, 8, seed=2, lights=lights)
+    ref = orc.render(cam, W, H, 0, 4, 1, 8, seed=2, lights=lights, accum_mode=1)
+    assert psnr(img[:, :, :3], ref[:, :, :3]) > 60.0
+    sc.set_option("traversal", 0)
+
+
+def test_render_textured_scene_matches_oracle(gpu):
+    """Texture fetch + Phong on a textured two-mesh scene (u8 image as diffuse and specular map)."""
+    import copy
+    from oracle import bindings as ob
+    from orion_amd import host
+    model = copy.deepcopy(conftest.load_model("view_test"))
+    rng = np.random.default_rng(4)
+    # give the quads distinct uvs so that the image texture is visible
+    for m in model.meshes:
+        m.vertices = m.vertices.copy()
+        m.vertices[:, 6:8] = (m.vertices[:, 0:2] * 1.7 - 0.3).astype(np.float32)
+    tex = host.Texture(rng.integers(0, 256, (16, 32, 3)).astype(np.uint8))
+    tex4 = host.Texture(rng.integers(0, 256, (8, 8, 4)).astype(np.uint8))
+    model.materials[model.meshes[0].material].tex_diffuse = tex
+    model.materials[model.meshes[0].material].tex_specular = tex
+    model.materials[model.meshes[1].material].tex_diffuse = tex4
+    sc = gpu.Scene(model, device=0)
+    orc = ob.OracleScene(model)
+    r = host.parse_rtc(os.path.join(conftest.ASSETS, "view_test.rtc"))
+    cam = gpu.camera_vectors(r.view_point, r.look_at, r.vector_up, r.y_view, 1.5)
+    img = sc.render(cam, 96, 64, 0, 4, 1, 3, seed=9, lights=r.lights)
+    ref = orc.render(cam, 96, 64, 0, 4, 1, 3, seed=9, lights=r.lights, accum_mode=1)
+    assert img[:, :, :3].max() > 0
+    assert psnr(img[:, :, :3], ref[:, :, :3]) > 60.0
+    sc.close()
+
+
+def test_render_shards_compose_exactly(gpu):
+    """Sample ranges and tiles add up to the full frame bit for bit (the multi-GPU decomposition),
+    whatever the batch size; device accumulators behave like host ones."""
+    import torch
+    sc = scene_for(gpu, "cornell")
+    W, H = 80, 48
+    eye, look, up, yv = CORNELL_CAM
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    full = sc.render(cam, W, H, 0, 6, 2, 10, seed=7)
+    part = sc.render(cam, W, H, 0, 2, 2, 10, seed=7)
+    part = sc.render(cam, W, H, 2, 6, 2, 10, seed=7, accum=part)
+    assert np.array_equal(bits(part), bits(full))
+    tiles = np.zeros((H, W, 4), np.float32)
+    for t in [(0, 0, 33, 20), (33, 0, W, 20), (0, 20, W, H)]:
+        tiles = sc.render(cam, W, H, 0, 6, 2, 10, seed=7, tile=t, accum=tiles)
+    assert np.array_equal(bits(tiles), bits(full))
+    sc.set_option("batch_paths", 5000)   # forces several batches per call
+    small = sc.render(cam, W, H, 0, 6, 2, 10, seed=7)
+    sc.set_option("batch_paths", 16 << 20)
+    assert np.array_equal(bits(small), bits(full))
+    dev = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    sc.render(cam, W, H, 0, 6, 2, 10, seed=7, accum=dev)
+    assert np.array_equal(bits(dev.cpu().numpy()), bits(full))
+
+
+def test_full_size_properties(gpu):
+    """At the benchmark's size (1920x1080) the oracle is too slow to compare against, so check what must
+    hold regardless: finite radiance, every pixel sampled, determinism, and that the primary-visibility
+    mask of the render equals the closest-hit query on the same camera rays."""
+    sc = scene_for(gpu, "cornell")
+    W, H = 1920, 1080
+    eye, look, up, yv = CORNELL_CAM
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    a = sc.render(cam, W, H, 0, 2, 2, 100, seed=1)
+    b = sc.render(cam, W, H, 0, 2, 2, 100, seed=1)
+    assert np.array_equal(bits(a), bits(b))
+    assert np.isfinite(a).all() and (a[:, :, 3] == 2).all() and (a[:, :, :3] >= 0).all()
+    # pixels whose unjittered centre ray and both neighbours miss must be black
+    c = cam
+    j, i = np.meshgrid(np.arange(W), np.arange(H))
+    x = (2 * (j.astype(np.float32) / np.float32(W)) - 1 + np.float32(1.0 / W)).astype(np.float32)
+    y = (2 * (i.astype(np.float32) / np.float32(H)) - 1 + np.float32(1.0 / H)).astype(np.float32)
+    d = (c[3:6][None, None] + x[..., None] * c[6:9][None, None] + (-y)[..., None] * c[9:12][None, None]).astype(np.float32)
+    o = np.broadcast_to(c[0:3], d.shape).astype(np.float32)
+    hit = (sc.closest_hit(o.reshape(-1, 3), d.reshape(-1, 3))["mesh"] != gpu.INVALID).reshape(H, W)
+    near = hit.copy()
+    near[1:] |= hit[:-1]; near[:-1] |= hit[1:]; near[:, 1:] |= hit[:, :-1]; near[:, :-1] |= hit[:, 1:]
+    assert (a[:, :, :3][~near] == 0).all()
+    assert a[:, :, :3][hit].mean() > 0

@@ -1,0 +1,105 @@
+"""Host layer (rtc parser, OBJ import, SBVH build) and the C-ABI library's exports.  CPU only."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import conftest
+from orion_amd import host
+
+RTC = {"cornell": "cornell-box.rtc", "view_test": "view_test.rtc", "hindu": "hindu.rtc", "nanosuit": "nanosuit.rtc"}
+
+
+@pytest.fixture(scope="module")
+def comp():
+    return np.load(os.path.join(conftest.GOLDEN, "components.npz"))
+
+
+@pytest.mark.parametrize("key", sorted(RTC))
+def test_parse_rtc_matches_reference(key, comp):
+    r = host.parse_rtc(os.path.join(conftest.ASSETS, RTC[key]))
+    ints, floats = comp[f"rtc_{key}_ints"], comp[f"rtc_{key}_floats"]
+    assert [r.recursion_level, r.xres, r.yres, len(r.lights)] == list(ints)
+    got = np.concatenate([[r.aspect_ratio], r.view_point, r.look_at, r.vector_up, [r.y_view]]).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), floats.view(np.uint32))
+    assert np.array_equal(r.lights.view(np.uint32), comp[f"rtc_{key}_lights"].view(np.uint32))
+    assert r.obj_file == bytes(comp[f"rtc_{key}_obj"]).decode()
+
+
+def test_parse_rtc_errors_and_roundtrip(tmp_path, capfd):
+    r = host.parse_rtc(str(tmp_path / "missing.rtc"))
+    assert "Error opening file" in capfd.readouterr().out
+    assert r.xres == 0 and r.obj_file == "" and len(r.lights) == 0
+    p = tmp_path / "a.rtc"
+    p.write_text("# c\n\n  m.obj \nt.png\n3\n 64 32\n1 2 3\n0 0 0\n0 1 0\n0.5\nX 1 2 3\nl 1 2 3 255 0 51 7\n")
+    r = host.parse_rtc(str(p))
+    assert "Invalid character 'X'" in capfd.readouterr().out
+    assert (r.obj_file, r.recursion_level, r.xres, r.yres, r.aspect_ratio, r.y_view) == ("m.obj", 3, 64, 32, 2.0, 0.5)
+    assert r.lights.shape == (1, 7) and r.lights[0, 3] == 1.0 and r.lights[0, 4] == 0.0 and r.lights[0, 6] == 7.0
+    q = tmp_path / "b.rtc"
+    host.write_rtc(str(q), r)
+    r2 = host.parse_rtc(str(q))
+    assert r2.obj_file == r.obj_file and r2.xres == 64 and np.allclose(r2.lights, r.lights, atol=1 / 255)
+    assert np.array_equal(r2.view_point, r.view_point)
+
+
+def test_obj_import_shapes():
+    m = conftest.load_model("cornell")
+    assert [x.n_triangles for x in m.meshes] == [2, 2, 2, 2, 2, 12, 12, 2]
+    assert [m.materials[x.material].name for x in m.meshes] == ["floor", "ceiling", "backWall", "rightWall", "leftWall", "shortBox", "tallBox", "light"]
+    light = m.materials[m.meshes[-1].material]
+    assert np.allclose(light.emissive, [4, 3.5, 3]) and np.allclose(light.diffuse, 0)
+    n = m.meshes[0].vertices[:, 3:6]
+    assert np.allclose(np.linalg.norm(n, axis=1), 1, atol=1e-6) and np.allclose(np.abs(n[:, 1]), 1, atol=1e-6)
+    assert conftest.load_model("nanosuit").n_triangles == 19058
+    assert conftest.load_model("hindu").n_triangles == 200
+    h = conftest.load_model("hindu")
+    assert h.materials[0].map_diffuse.endswith("basecolor_.jpg")
+    uv = h.meshes[0].vertices[:, 6:8]
+    assert uv.min() >= -1e-6 and uv.max() <= 1 + 1e-6
+    vt = conftest.load_model("view_test")
+    assert [x.n_triangles for x in vt.meshes] == [2, 2] and np.allclose(vt.meshes[0].vertices[:, 3:6], [0, 0, 1])
+
+
+@pytest.mark.parametrize("name", ["cornell", "view_test", "hindu", "nanosuit", "soup"])
+@pytest.mark.parametrize("strategy,tag", [(host.MEDIAN, "median"), (host.MIDDLE, "middle"), (host.SAH, "sah")])
+def test_host_bvh_matches_reference(name, strategy, tag):
+    g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
+    if name == "soup":
+        import raygen
+        v, i = raygen.triangle_soup()
+        model = host.model_from_arrays(v, i, strategy)
+    else:
+        model = host.load_model(conftest.scene_path(name), strategy)
+    for mi, m in enumerate(model.meshes):
+        assert np.array_equal(m.tri_order, g[f"tree_{tag}_{mi}_perm"])
+        # walk the index-linked tree in preorder and compare with the reference's dump
+        order, stack = [], [0]
+        while stack:
+            k = stack.pop()
+            order.append(k)
+            if not m.nodes[k]["is_leaf"]:
+                stack.append(int(m.nodes[k]["child"][1])); stack.append(int(m.nodes[k]["child"][0]))
+        nd = m.nodes[order]
+        meta = np.stack([nd["is_leaf"], nd["begin"], nd["end"]], 1)
+        assert np.array_equal(meta, g[f"tree_{tag}_{mi}_meta"])
+        boxes = np.concatenate([nd["lo"], nd["hi"]], 1)
+        assert np.array_equal(boxes.view(np.uint32), g[f"tree_{tag}_{mi}_boxes"].view(np.uint32))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/orion_hip.h declares."""
+    from orion_amd import api
+    header = open(os.path.join(conftest.ROOT, "include", "orion_hip.h")).read()
+    declared = set(re.findall(r"\b(orion_hip_\w+)\s*\(", header))
+    assert len(declared) >= 10
+    L = ctypes.CDLL(api.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} is declared but not exported"
+    L.orion_hip_last_error.restype = ctypes.c_char_p
+    assert L.orion_hip_last_error() == b""
+    # argument validation works without touching a device
+    assert L.orion_hip_closest_hit(None, None, None, 1, None) != 0
+    assert b"scene is null" in L.orion_hip_last_error()
