@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: the Cornell-box BRDF path tracer at 1920x1080, depth 100, 2 light samples
+(the README render of the reference, BASELINE.json configs[1]) on N MI355X GPUs of one node.
+
+A step renders `--spp-per-step` samples of every pixel on each rank (ranks own disjoint sample
+ranges; weak scaling) into a device-resident accumulator, followed for N > 1 by one RCCL sum of
+the accumulators -- the only exchange the workload has.  value = pixel-samples/s over all ranks.
+
+    python bench.py --gpus 1 --steps 4 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
+  roofline      HBM roofline of the dominant kernel from live HIP-event timings
+  cpu_baseline  the oracle's render of a bounded sample of the same frame on the host cores
+  rays          traversal throughput (closest-hit queries/s) over the timed region
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+MAX_DEPTH, LIGHT_SAMPLES, FULL_SPP = 100, 2, 2048
+CAMERA = ([-0.10141, 1, 3.00498], [-0.10141, 1, 2.00498], [0, 1, 0], 1.0)   # assets/cornell-box.rtc
+PUBLISHED_SAMPLES_PER_S = 1920 * 1080 * 2048 / 5126.4                        # reference README.md:38-46
+HBM_PEAK_GBS = 8000.0                                                        # MI355X HBM3E peak
+# Algorithmic queue bytes: 32 B ray record read + 32 B hit record written per closest-hit query;
+# a shaded path vertex adds L*E such queries for its light samples and 48 B + 48 B of path state.
+BYTES_PER_RAY = 64
+BYTES_PER_VERTEX_STATE = 96
+
+
+def cpu_baseline(model, cam, target_s=12.0):
+    """Time the oracle (CPU restatement, OpenMP over pixels) on a scaled-down frame of the same scene,
+    camera, depth and light samples; returns samples/s on this host's cores."""
+    from oracle import bindings as ob
+    sc = ob.OracleScene(model)
+    threads = min(ob.oracle_lib().oracle_max_threads(), len(os.sched_getaffinity(0)))
+    w, h = 160, 90
+    t0 = time.time()
+    sc.render(cam, w, h, 0, 2, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=threads)
+    probe = time.time() - t0
+    rate = w * h * 2 / max(probe, 1e-6)
+    spp = int(max(2, min(64, target_s * rate / (480 * 270))))
+    w, h = 480, 270
+    t0 = time.time()
+    sc.render(cam, w, h, 0, spp, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=threads)
+    dt = time.time() - t0
+    return {"value": w * h * spp / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{w}x{h} x {spp} spp of the same Cornell frame (depth {MAX_DEPTH}, {LIGHT_SAMPLES} light samples), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not collect per-kernel HIP-event timings")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from orion_amd import api, host
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    model = host.load_model(os.path.join(ROOT, "tests", "golden", "assets", "cornell-box", "cornell-box.obj"))
+    eye, look, up, yv = CAMERA
+    cam = api.camera_vectors(eye, look, up, yv, W / H)
+    scene = api.Scene(model, device=local)
+    scene.set_option("traversal", args.traversal)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    spp = args.spp_per_step
+
+    def step(index):
+        base = (index * world + rank) * spp
+        scene.render(cam, W, H, base, base + spp, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accum)
+        if world > 1:
+            dist.all_reduce(accum)   # the frame's one exchange: sum of the radiance accumulators
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        accum.zero_()
+        step(i)
+    scene.profile(not args.no_profile)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        accum.zero_()
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stats = scene.profile_read()
+    scene.profile(False)
+
+    samples = W * H * spp * args.steps * world
+    value = samples / dt
+    out = {
+        "metric": "samples/s (pixel-samples per second, Cornell box 1920x1080 BRDF path tracer)",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": value / PUBLISHED_SAMPLES_PER_S, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cornell-box BRDF path tracer 1920x1080, max depth 100, 2 light samples "
+                               "(BASELINE.json configs[1]); one step = %d spp of the full frame per GPU" % spp,
+                   "spp_per_step_per_gpu": spp, "seed": 1, "rng": "philox4x32-10 counter",
+                   "sharding": "sample-index ranges per rank + one RCCL all-reduce of the accumulator per step"},
+        "projected_wall_s_2048spp": W * H * FULL_SPP / value,
+    }
+    if rank == 0:
+        E = sum(1 for m in model.meshes if np.any(model.materials[m.material].emissive != 0))
+        kern = {}
+        for name, per_item in (("closest_hit", BYTES_PER_RAY),
+                               ("shade", BYTES_PER_RAY * LIGHT_SAMPLES * E + BYTES_PER_VERTEX_STATE)):
+            s = stats[name]
+            if s["launches"]:
+                gbs = s["items"] * per_item / (s["ms"] * 1e-3) / 1e9
+                kern[name] = {"launches": s["launches"], "items": s["items"], "ms": s["ms"],
+                              "avg_launch_ms": s["ms"] / s["launches"], "algorithmic_GBs": gbs}
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]["ms"])
+            out["roofline"] = {"bound": "hbm", "kernel": "k_extend" if dom == "closest_hit" else "k_shade",
+                               "achieved": kern[dom]["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": kern[dom]["algorithmic_GBs"] / HBM_PEAK_GBS, "traffic": None}
+            out["kernels"] = kern
+            # closest-hit queries issued per second: extend rays + the light-sample rays traced inside shade
+            rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
+            out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
+                           "Mrays_per_s_per_gpu": rays / dt / 1e6,
+                           "note": "closest-hit queries traced by rank 0 over the timed region / wall time"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, cam)
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

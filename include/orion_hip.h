@@ -118,7 +118,8 @@ typedef struct OrionRenderParams {
 /* Per-kernel timing collected with HIP events on the scene's stream while
  * profiling is enabled. */
 #define ORION_KERNEL_CLOSEST_HIT 0   /* closest-hit traversal (extend rays and orion_hip_closest_hit) */
-#define ORION_KERNEL_SHADOW      1   /* light-sample / shadow traversal + direct-light evaluation */
+#define ORION_KERNEL_SHADOW      1   /* light-sample / shadow rays: traced inside the shade launch, so only
+                                        `items` (rays traced) is counted here; their time is part of SHADE */
 #define ORION_KERNEL_SHADE       2   /* surface evaluation, roulette, next-ray generation */
 #define ORION_KERNEL_GENERATE    3   /* primary-ray generation */
 #define ORION_KERNEL_RESOLVE     4   /* per-sample accumulation into the image */

@@ -46,15 +46,31 @@ __device__ __forceinline__ HitRec miss_rec() { HitRec h; h.t = INFINITY; h.u = 0
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// Wave-level queue append: one atomic per wave, slots in lane order.
-__device__ __forceinline__ uint32_t queue_slot(bool push, uint32_t* counter) {
+// Block-level queue append.  Every thread of the block must call it.  Survivors are
+// counted per wave with a ballot, the four wave counts are combined through LDS and
+// ONE 64-bit atomic per block reserves the slots (low word: queue length, high word:
+// a statistics counter, here the number of shaded vertices).  One atomic per wave on a
+// single address would serialise at the memory side (~12 ns each) and bound the kernel.
+__device__ __forceinline__ uint32_t queue_slot(bool push, bool stat, unsigned long long* counter) {
+    __shared__ uint32_t s_cnt[kBlock / 64];
+    __shared__ uint32_t s_stat[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t wave = threadIdx.x >> 6;
     const uint64_t m = __ballot(push);
-    const uint32_t cnt = (uint32_t)__popcll(m);
-    uint32_t base = 0;
-    if (cnt) {
-        if (lane_id() == 0) base = atomicAdd(counter, cnt);
-        base = __shfl(base, 0);
+    const uint64_t ms = __ballot(stat);
+    if (lane_id() == 0) { s_cnt[wave] = (uint32_t)__popcll(m); s_stat[wave] = (uint32_t)__popcll(ms); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0, stat_total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) { total += s_cnt[w]; stat_total += s_stat[w]; }
+        unsigned long long old = 0;
+        if (total | stat_total) old = atomicAdd(counter, (unsigned long long)total | ((unsigned long long)stat_total << 32));
+        s_base = (uint32_t)old;
     }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (uint32_t w = 0; w < wave; w++) base += s_cnt[w];
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     return base + rank;
 }
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues q, uint32
 // (orion/raytracer.cpp:116-206).  POINT selects the point-light branch.
 template <int MODE, bool POINT>
 __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, uint32_t depth, Queues qin, uint32_t n,
-                                                  const HitRec* __restrict__ hits, Queues qout, uint32_t* __restrict__ out_count,
+                                                  const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
                                                   float4* __restrict__ rad) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool live = i < n;
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
         }
     }
 
-    const uint32_t slot = queue_slot(cont, out_count);
+    const uint32_t slot = queue_slot(cont, live, out_count);
     if (cont) {
         qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
         qout.d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
@@ -760,7 +776,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     if (int rc = s->hits.reserve(max_paths * 16)) return rc;
     if (int rc = s->rad.reserve(max_paths * 16)) return rc;
     if (int rc = s->counter.reserve(64)) return rc;
-    uint32_t* d_count = static_cast<uint32_t*>(s->counter.p);
+    unsigned long long* d_count = static_cast<unsigned long long*>(s->counter.p);
     Queues qa{static_cast<float4*>(s->q[0].p), static_cast<float4*>(s->q[1].p), static_cast<float4*>(s->q[2].p)};
     Queues qb{static_cast<float4*>(s->q[3].p), static_cast<float4*>(s->q[4].p), static_cast<float4*>(s->q[5].p)};
     HitRec* d_hits = static_cast<HitRec*>(s->hits.p);
@@ -782,7 +798,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                 if (mode == MODE_WAVE) hipLaunchKernelGGL(k_extend<MODE_WAVE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, qin, n, d_hits);
                 else hipLaunchKernelGGL(k_extend<MODE_LANE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, qin, n, d_hits);
             }
-            HIP_TRY(hipMemsetAsync(d_count, 0, 4, s->stream));
+            HIP_TRY(hipMemsetAsync(d_count, 0, 8, s->stream));
             {
                 Profiled prof(s, ORION_KERNEL_SHADE, n);
                 const dim3 g(grid_for(n)), b(kBlock);
@@ -795,9 +811,14 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                 }
             }
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(s->h_count, d_count, 4, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(s->h_count, d_count, 8, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
-            n = *s->h_count;
+            n = s->h_count[0];
+            if (s->profiling) {   // light-sample / shadow rays traced inside the shade launch
+                const uint64_t per_vertex = point ? p->n_lights : (uint64_t)p->light_samples * s->view.n_emissive;
+                s->stats[ORION_KERNEL_SHADOW].launches++;
+                s->stats[ORION_KERNEL_SHADOW].items += (uint64_t)s->h_count[1] * per_vertex;
+            }
             Queues t = qin; qin = qout; qout = t;
         }
         {
