@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Closest-hit throughput (Mrays/s) of the traversal kernels on device-resident ray batches,
+timed with the library's HIP events.  Usage: python tools/bench_rays.py [scene ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import conftest  # noqa: E402
+import raygen  # noqa: E402
+
+
+def main():
+    import torch
+    from orion_amd import api
+    scenes = sys.argv[1:] or ["cornell", "hindu", "nanosuit", "soup"]
+    n = 1 << 22
+    for name in scenes:
+        model = conftest.load_model(name)
+        sc = api.Scene(model, device=0)
+        eye, look, up, yv = raygen.default_camera(model) if name != "cornell" else ([-0.10141, 1, 3.00498], [-0.10141, 1, 2.00498], [0, 1, 0], 1.0)
+        cam = api.camera_vectors(eye, look, up, yv, 16 / 9)
+        o1, d1 = raygen.primary_rays(cam, 1920, 1080, n, seed=1)
+        # sort primary rays by pixel so that waves are coherent, as the generate kernel's are
+        batches = {"R1 primary": (o1, d1)}
+        h = sc.closest_hit(o1, d1)
+        hit = h["mesh"] != api.INVALID
+        # bounce rays: geometric normal from the oracle-free route: use interpolated normals of the hit triangle's first vertex
+        nrm = np.zeros((n, 3), np.float32)
+        for mi, m in enumerate(model.meshes):
+            sel = np.where(h["mesh"] == mi)[0]
+            if len(sel):
+                nrm[sel] = m.vertices[m.indices[3 * h["tri"][sel]], 3:6]
+        ids = np.stack([h["mesh"], h["tri"]], 1)
+        tuv = np.stack([h["t"], h["u"], h["v"]], 1)
+        o2, d2 = raygen.bounce_rays(o1, d1, ids, tuv, nrm, seed=2)
+        if len(o2) > 1000:
+            rep = int(np.ceil(n / len(o2)))
+            o2 = np.tile(o2, (rep, 1))[:n]; d2 = np.tile(d2, (rep, 1))[:n]
+            perm = np.random.default_rng(5).permutation(n)
+            batches["R2 bounce"] = (o2[perm], d2[perm])
+            o3, d3 = raygen.rays_to_surface(o2[perm], model, seed=3)
+            batches["R3 shadow"] = (o3, d3)
+        for mode, tag in ((1, "lane"), (2, "wave")):
+            if tag == "wave" and model.n_triangles > 2000:
+                continue
+            sc.set_option("traversal", mode)
+            for bname, (o, d) in batches.items():
+                to, td = torch.from_numpy(np.ascontiguousarray(o)).cuda(), torch.from_numpy(np.ascontiguousarray(d)).cuda()
+                out = torch.empty((len(o), 5), dtype=torch.int32, device="cuda")
+                sc.closest_hit(to, td, out)
+                sc.profile(True)
+                for _ in range(5):
+                    sc.closest_hit(to, td, out)
+                st = sc.profile_read()["closest_hit"]
+                sc.profile(False)
+                print(f"{name:9s} {tag:5s} {bname:11s} rays {len(o):8d}  {st['items'] / st['ms'] / 1e3:9.1f} Mrays/s  ({st['ms'] / st['launches']:.3f} ms/launch)", flush=True)
+        sc.close()
+
+
+if __name__ == "__main__":
+    main()
