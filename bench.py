@@ -42,13 +42,12 @@ def cpu_baseline(model, cam, target_s=12.0):
     from oracle import bindings as ob
     sc = ob.OracleScene(model)
     threads = min(ob.oracle_lib().oracle_max_threads(), len(os.sched_getaffinity(0)))
-    w, h = 160, 90
-    t0 = time.time()
-    sc.render(cam, w, h, 0, 2, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=threads)
-    probe = time.time() - t0
-    rate = w * h * 2 / max(probe, 1e-6)
-    spp = int(max(2, min(64, target_s * rate / (480 * 270))))
     w, h = 480, 270
+    t0 = time.time()
+    sc.render(cam, w, h, 0, 4, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=threads)
+    probe = time.time() - t0
+    rate = w * h * 4 / max(probe, 1e-6)
+    spp = int(max(4, min(8192, target_s * rate / (w * h))))
     t0 = time.time()
     sc.render(cam, w, h, 0, spp, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=threads)
     dt = time.time() - t0
@@ -61,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=32)
     ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not collect per-kernel HIP-event timings")

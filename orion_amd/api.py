@@ -75,6 +75,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise OrionError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        try:
+            # torch ships its own copy of the HIP runtime; importing it first makes this process use that
+            # one copy for both (loading the system runtime first leaves torch without a device)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.orion_hip_last_error.restype = C.c_char_p
         L.orion_hip_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,

@@ -110,9 +110,9 @@ __global__ __launch_bounds__(kBlock) void k_anyhit_api(SceneView S, const float*
 
 // --- path tracing --------------------------------------------------------------
 struct Queues {
-    float4* o;    // origin.xyz, path id
-    float4* d;    // direction.xyz
-    float4* T;    // throughput.xyz
+    float4* o;    // origin.xyz, path id (index of the path's radiance slot)
+    float4* d;    // direction.xyz, pixel index (RNG counter word 0)
+    float4* T;    // throughput.xyz, absolute sample index (RNG counter word 1)
 };
 
 __device__ __forceinline__ void path_pixel(const FrameParams& F, uint32_t pid, uint32_t& pixel, uint32_t& sample, uint32_t& px, uint32_t& py) {
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, uint32_t n_p
     const float xs = x + jx, ys = -(y + jy);
     const V3 dir = (ld3(F.front) + ld3(F.right) * xs) + ld3(F.up) * ys;
     q.o[pid] = make_float4(F.eye[0], F.eye[1], F.eye[2], __uint_as_float(pid));
-    q.d[pid] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-    q.T[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    q.d[pid] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pixel));
+    q.T[pid] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
     rad[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
@@ -166,12 +166,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool live = i < n;
     V3 o = splat(0.0f), d = splat(1.0f), T = splat(0.0f);
-    uint32_t pid = 0;
+    uint32_t pid = 0, pixel = 0, sample = 0;
     HitRec h = miss_rec();
     if (live) {
         const float4 a = qin.o[i], b = qin.d[i], c = qin.T[i];
         o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); T = mk(c.x, c.y, c.z);
-        pid = __float_as_uint(a.w);
+        pid = __float_as_uint(a.w); pixel = __float_as_uint(b.w); sample = __float_as_uint(c.w);
         const float4 hr = reinterpret_cast<const float4*>(hits)[i];
         h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
         live = h.gtri != kInvalid;   // a miss contributes nothing and ends the path (orion/raytracer.cpp:113-114)
@@ -181,10 +181,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
     V3 normal = splat(0.0f), hitPos = splat(0.0f), biased = splat(0.0f), color = splat(0.0f);
     float tu = 0.0f, tv = 0.0f;
     uint32_t mesh_id = 0;
-    uint32_t pixel = 0, sample = 0;
     if (live) {
-        uint32_t px, py;
-        path_pixel(F, pid, pixel, sample, px, py);
         const Surface sf = surface_at(S, h.gtri, h.u, h.v);
         mesh_id = sf.mesh; tu = sf.tu; tv = sf.tv;
         normal = normalize(sf.normal);
@@ -245,7 +242,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
                     V3 tangent = cross(normal, mk(0.0f, 1.0f, 0.0f));
                     if (dot(tangent, tangent) == 0.0f) tangent = cross(normal, mk(0.0f, 0.0f, 1.0f));
                     const V3 bitangent = cross(normal, tangent);
-                    const float a = sin_theta * cosf(psi), b = sin_theta * sinf(psi), c = cos_theta;
+                    float sin_psi, cos_psi;
+                    sincosf(psi, &sin_psi, &cos_psi);
+                    const float a = sin_theta * cos_psi, b = sin_theta * sin_psi, c = cos_theta;
                     next_d = (tangent * a + bitangent * b) + normal * c;
                     next_T = (T * kd) / cc;
                     cont = true;
@@ -287,8 +286,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
     const uint32_t slot = queue_slot(cont, live, out_count);
     if (cont) {
         qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
-        qout.d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
-        qout.T[slot] = make_float4(next_T.x, next_T.y, next_T.z, 0.0f);
+        qout.d[slot] = make_float4(next_d.x, next_d.y, next_d.z, __uint_as_float(pixel));
+        qout.T[slot] = make_float4(next_T.x, next_T.y, next_T.z, __uint_as_float(sample));
     }
 }
 
@@ -353,7 +352,7 @@ struct OrionScene {
     uint32_t n_nodes = 0, n_tris = 0;
     // options
     int traversal = 0;                // 0 auto, 1 lane, 2 wave
-    uint64_t batch_paths = 16u << 20;
+    uint64_t batch_paths = 64u << 20;     // paths in flight per batch (128 B of queues each)
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
     DevBuf q[6], hits, rad, counter;

@@ -23,8 +23,10 @@ struct Words4 { uint32_t w[4]; };
 __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // full 32x32->64 products: one v_mad_u64_u32 each instead of a mul_hi/mul_lo pair
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -63,13 +65,16 @@ __device__ __forceinline__ int f2i_x86(float x) {
 __device__ __forceinline__ V3 tex_fetch(const SceneView& S, uint32_t tex, float x, float y) {
     const Texture T = S.textures[tex];
     const int w = (int)T.width, hgt = (int)T.height;
-    int ui = f2i_x86(x * (float)w);
-    int vi = f2i_x86(y * (float)hgt);
-    ui %= w;
-    vi %= hgt;
-    if (ui < 0) ui = w + ui;
-    if (vi < 0) vi = hgt + vi;
-    const uint32_t texel = (uint32_t)(w * vi + ui);
+    uint32_t texel = 0;
+    if ((T.width | T.height) != 1u) {   // a 1x1 texture (every solid colour) maps any (x, y) to texel 0
+        int ui = f2i_x86(x * (float)w);
+        int vi = f2i_x86(y * (float)hgt);
+        ui %= w;
+        vi %= hgt;
+        if (ui < 0) ui = w + ui;
+        if (vi < 0) vi = hgt + vi;
+        texel = (uint32_t)(w * vi + ui);
+    }
     if (T.format == 0u) {
         const float* p = S.texels_f32 + T.offset + 3u * texel;
         return mk(p[0], p[1], p[2]);
@@ -131,7 +136,8 @@ __device__ __forceinline__ V3 color_phong(V3 ka, V3 kd, V3 ks, float shininess, 
 // TracedMesh::randomPointOnSurface + Triangle::randomPointOnSurface
 // (orion/mesh.hpp:179-184, orion/geometry.hpp:160-171), draws taken from one Philox block.
 __device__ __forceinline__ void light_point(const SceneView& S, const Mesh& lm, Words4 r, V3& point, float& bias) {
-    const uint32_t ri = r.w[0] % lm.n_tri;
+    // x % n without the division when n is a power of two (same value)
+    const uint32_t ri = (lm.n_tri & (lm.n_tri - 1u)) == 0u ? (r.w[0] & (lm.n_tri - 1u)) : (r.w[0] % lm.n_tri);
     const uint32_t slot = S.slot_of[lm.tri_base + ri];
     const float4* tp = reinterpret_cast<const float4*>(S.tris + slot);
     const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
