@@ -1,0 +1,104 @@
+"""The five BASELINE.json configs (derived .rtc files under configs/) through the HIP path against the
+oracle, at the config's own size where the oracle finishes in seconds and at reduced resolution / spp
+otherwise (same camera, depth and lights).  Also SAH-built trees and image textures at scale."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import conftest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = os.path.join(conftest.ROOT, "configs")
+
+
+def psnr(a, b):
+    peak = float(np.abs(b).max())
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 999.0 if mse == 0 else 10 * np.log10(peak * peak / mse)
+
+
+def frame(name):
+    from orion_amd import api
+    return api.load_frame(os.path.join(CONFIGS, name + ".rtc"), load_textures=False)
+
+
+def compare(fr, width, height, spp, light_samples, model=None, strategy=0, min_psnr=60.0):
+    from oracle import bindings as ob
+    from orion_amd import api
+    model = model or fr.model
+    cam = api.camera_vectors(fr.rtc.view_point, fr.rtc.look_at, fr.rtc.vector_up, fr.rtc.y_view, width / height)
+    sc = api.Scene(model, device=0)
+    img = sc.render(cam, width, height, 0, spp, light_samples, fr.rtc.recursion_level, seed=11, lights=fr.rtc.lights)
+    sc.close()
+    ref = ob.OracleScene(model, strategy=strategy).render(cam, width, height, 0, spp, light_samples, fr.rtc.recursion_level,
+                                                          seed=11, lights=fr.rtc.lights, accum_mode=1)
+    assert np.isfinite(img).all() and (img[:, :, 3] == spp).all()
+    assert img[:, :, :3].max() > 0, "image is black"
+    p = psnr(img[:, :, :3], ref[:, :, :3])
+    assert p > min_psnr, f"PSNR {p:.1f} dB"
+    return img
+
+
+def test_c0_cornell_point_light_full_config():
+    fr = frame("c0_cornell_point_256")
+    assert (fr.rtc.xres, fr.rtc.yres, fr.rtc.recursion_level, len(fr.rtc.lights)) == (256, 256, 8, 1)
+    compare(fr, 256, 256, 16, 1)
+
+
+def test_c1_cornell_brdf_reduced():
+    fr = frame("c1_cornell_brdf_fhd")
+    assert (fr.rtc.xres, fr.rtc.yres, fr.rtc.recursion_level, len(fr.rtc.lights)) == (1920, 1080, 100, 0)
+    compare(fr, 240, 135, 8, 2)
+
+
+def test_c2_view_test_reduced():
+    fr = frame("c2_view_test_fhd")
+    compare(fr, 480, 270, 8, 1)
+
+
+@pytest.mark.parametrize("strategy,tag", [(0, "median"), (2, "sah")])
+def test_c3_nanosuit_reduced(strategy, tag):
+    """Deep trees, per-lane traversal; the SAH-built tree (reference's own alternative strategy) gives
+    the same picture up to exact ties and must match the oracle built the same way."""
+    from orion_amd import host
+    fr = frame("c3_nanosuit_fhd")
+    model = host.load_model(conftest.scene_path("nanosuit"), strategy)
+    assert model.n_triangles == 19058
+    compare(fr, 240, 135, 4, 1, model=model, strategy=strategy)
+
+
+def test_c4_hindu_tiles_and_sample_shards():
+    from orion_amd import api, dist as odist
+    fr = frame("c4_hindu_4k")
+    W, H, SPP = 384, 216, 8
+    full = compare(fr, W, H, SPP, 1)
+    cam = api.camera_vectors(fr.rtc.view_point, fr.rtc.look_at, fr.rtc.vector_up, fr.rtc.y_view, W / H)
+    sc = api.Scene(fr.model, device=0)
+    acc = np.zeros((H, W, 4), np.float32)
+    for rank in range(8):   # what 8 ranks would render, summed in rank order
+        part = np.zeros((H, W, 4), np.float32)
+        for rect, b, e in odist.shard_plan(SPP, W, H, rank, 8, tiles=(4, 2)):
+            sc.render(cam, W, H, b, e, 1, fr.rtc.recursion_level, seed=11, lights=fr.rtc.lights, tile=rect, accum=part)
+        acc += part
+    sc.close()
+    assert np.array_equal(acc[:, :, 3], full[:, :, 3])
+    np.testing.assert_allclose(acc[:, :, :3], full[:, :, :3], rtol=2e-6, atol=1e-6)
+
+
+def test_image_textures_at_scale():
+    """A 1024x1024 RGB and a 512x512 RGBA image as diffuse/specular maps on hindu's uv layout."""
+    from orion_amd import host
+    fr = frame("c4_hindu_4k")
+    model = copy.deepcopy(fr.model)
+    rng = np.random.default_rng(8)
+    big = host.Texture(rng.integers(0, 256, (1024, 1024, 3)).astype(np.uint8))
+    mat = model.materials[model.meshes[0].material]
+    mat.tex_diffuse = big
+    mat.tex_specular = host.Texture(rng.integers(0, 256, (512, 512, 4)).astype(np.uint8))
+    fr2 = copy.copy(fr)
+    fr2.rtc = copy.deepcopy(fr.rtc)
+    fr2.rtc.recursion_level = 2
+    compare(fr2, 256, 144, 4, 1, model=model)

@@ -45,6 +45,18 @@ def main():
             batches["R2 bounce"] = (o2[perm], d2[perm])
             o3, d3 = raygen.rays_to_surface(o2[perm], model, seed=3)
             batches["R3 shadow"] = (o3, d3)
+            if name == "cornell":
+                # shadow rays as the path tracer casts them: towards the light mesh only
+                import copy
+                lm = copy.copy(model); lm.meshes = [model.meshes[-1]]
+                o4, d4 = raygen.rays_to_surface(o2[perm], lm, seed=4)
+                batches["R4 to-light"] = (o4, d4)
+                # the same rays grouped by the surface they start on (mesh, triangle of the previous hit)
+                key = (ids[hit][:, 0].astype(np.int64) * 1000 + ids[hit][:, 1])
+                key = np.tile(key, rep)[:n][perm]
+                order = np.argsort(key, kind="stable")
+                batches["R4 binned"] = (o4[order], d4[order])
+                batches["R2 binned"] = (o2[perm][order], d2[perm][order])
         for mode, tag in ((1, "lane"), (2, "wave")):
             if tag == "wave" and model.n_triangles > 2000:
                 continue

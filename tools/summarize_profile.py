@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs (kernel stats CSV + PMC counter_collection CSVs) into a small
+per-kernel text summary for profiles/.  Usage: summarize_profile.py <gpurun_out prefix> <out.md>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def kname(n):
+    for k in ("k_shade", "k_extend", "k_generate", "k_resolve", "k_query_api"):
+        if k in n:
+            return k
+    return None
+
+
+def main():
+    prefix, out = sys.argv[1], sys.argv[2]
+    lines = []
+    trace = glob.glob(prefix + "trace/*kernel_stats.csv")
+    if trace:
+        lines.append("## rocprofv3 --kernel-trace --stats (kernel, calls, total ms, average us, % of GPU time)\n")
+        for r in csv.DictReader(open(trace[0])):
+            lines.append(f"- `{r['Name'][:70]}` calls {r['Calls']}  total {int(r['TotalDurationNs']) / 1e6:.3f} ms  avg {float(r['AverageNs']) / 1e3:.1f} us  {float(r['Percentage']):.2f} %")
+        b = prefix + "trace/bench.json"
+        if os.path.exists(b):
+            d = json.load(open(b))
+            lines.append(f"\nbench.py under the profiler: {d['value'] / 1e9:.3f} Gsamples/s, HIP-event kernel totals: " +
+                         ", ".join(f"{k} {v['ms']:.3f} ms / {v['launches']} launches" for k, v in d.get("kernels", {}).items()))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.Counter()
+    for f in glob.glob(prefix + "*/p_counter_collection.csv"):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            if not k:
+                continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if (f, r["Dispatch_Id"]) not in seen:
+                seen.add((f, r["Dispatch_Id"]))
+        for r in csv.DictReader(open(f)):
+            pass
+    if agg:
+        lines.append("\n## PMC counters summed over all dispatches of the run (separate passes per counter group)\n")
+        for k, v in agg.items():
+            lines.append(f"### {k}")
+            for c, x in sorted(v.items()):
+                lines.append(f"- {c}: {x:.6g}")
+            if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+                # FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads
+                rd = v.get("FETCH_SIZE", 0) * 1024 * 2
+                wr = v.get("WRITE_SIZE", 0) * 1024
+                lines.append(f"- HBM traffic (FETCH_SIZE x2 per the gfx950 correction, + WRITE_SIZE): read {rd / 1e9:.3f} GB, write {wr / 1e9:.3f} GB")
+            if "TCC_HIT_sum" in v:
+                lines.append(f"- L2 hit rate: {v['TCC_HIT_sum'] / max(1, v['TCC_HIT_sum'] + v['TCC_MISS_sum']):.4f}")
+            if "SQ_INSTS_VALU" in v and "SQ_WAVES" in v:
+                lines.append(f"- per wave: {v['SQ_INSTS_VALU'] / v['SQ_WAVES']:.0f} VALU, {v['SQ_INSTS_SALU'] / v['SQ_WAVES']:.0f} SALU, {v['SQ_INSTS_SMEM'] / v['SQ_WAVES']:.0f} SMEM instructions; "
+                             f"waiting share SQ_WAIT_ANY/SQ_WAVE_CYCLES = {v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.2f}")
+            lines.append("")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
