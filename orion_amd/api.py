@@ -16,7 +16,8 @@ import numpy as np
 from . import host
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborion_hip.so")
+# ORION_HIP_LIB selects another build of the same library (A/B measurements)
+LIB_PATH = os.environ.get("ORION_HIP_LIB") or os.path.join(_HERE, "liborion_hip.so")
 
 INVALID = 0xFFFFFFFF
 

@@ -143,28 +143,91 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, uint32_t n_p
     rad[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
+#ifndef ORION_RAYS_PER_THREAD
+#define ORION_RAYS_PER_THREAD 4
+#endif
+constexpr uint32_t kRaysPerThread = ORION_RAYS_PER_THREAD;
+constexpr uint32_t kTile = kBlock * kRaysPerThread;   // rays per block
+constexpr uint32_t kMaxBins = 64;
+
+// Closest hit of every queued ray (orion/model.hpp:52-62).  Rays that miss end here: a miss
+// contributes nothing (orion/raytracer.cpp:113-114).  Rays that hit leave as complete path-vertex
+// records (origin, direction, throughput, ids + hit), compacted into `qout`/`hits`, and inside
+// each block's tile of kTile rays they are grouped by the triangle they hit (a counting sort
+// through LDS).  The shade kernel that consumes them therefore runs on waves whose vertices lie
+// on the same surface: its light-sample rays start on one plane and aim at one light, so the
+// wave-synchronous traversal's early exits hold for whole waves, and its material fetches are
+// uniform.  n_bins = number of triangle bins (<= kMaxBins; larger ids share the last bin), 1 = no grouping.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues q, uint32_t n, HitRec* __restrict__ hits) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = i < n;
-    V3 o = splat(0.0f), d = splat(1.0f);
-    if (active) {
-        const float4 a = q.o[i], b = q.d[i];
-        o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
+__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues qin, uint32_t n, Queues qout, HitRec* __restrict__ hits,
+                                                   unsigned long long* __restrict__ counter, uint32_t n_bins) {
+    __shared__ float4 s_hit[kTile];
+    __shared__ uint16_t s_rank[kTile];
+    __shared__ uint32_t s_cnt[kMaxBins];
+    __shared__ uint32_t s_off[kMaxBins];
+    __shared__ uint32_t s_base;
+    const uint32_t tile0 = blockIdx.x * kTile;
+    if (threadIdx.x < kMaxBins) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t k = 0; k < kRaysPerThread; k++) {
+        const uint32_t slot = k * kBlock + threadIdx.x;
+        const uint32_t i = tile0 + slot;
+        const bool active = i < n;
+        V3 o = splat(0.0f), d = splat(1.0f);
+        if (active) {
+            const float4 a = qin.o[i], b = qin.d[i];
+            o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
+        }
+        HitRec h = miss_rec();
+        traverse<MODE, false>(S, o, d, h, active);
+        s_hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.gtri));
+        if (h.gtri != kInvalid) {
+            const uint32_t bin = min(h.gtri, n_bins - 1u);
+            s_rank[slot] = (uint16_t)atomicAdd(&s_cnt[bin], 1u);
+        }
     }
-    HitRec h = miss_rec();
-    traverse<MODE, false>(S, o, d, h, active);
-    if (active) reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.gtri));
+    __syncthreads();
+    if (threadIdx.x < 64) {   // exclusive scan of the bin counts by the first wave (kMaxBins == 64 lanes)
+        const uint32_t c = s_cnt[threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t up = __shfl_up(incl, sft);
+            if ((int)threadIdx.x >= sft) incl += up;
+        }
+        s_off[threadIdx.x] = incl - c;
+        if (threadIdx.x == 63) s_base = incl ? (uint32_t)atomicAdd(counter, (unsigned long long)incl) : 0u;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t k = 0; k < kRaysPerThread; k++) {
+        const uint32_t slot = k * kBlock + threadIdx.x;
+        const float4 h = s_hit[slot];
+        const uint32_t gtri = __float_as_uint(h.w);
+        if (gtri != kInvalid) {
+            const uint32_t i = tile0 + slot;
+            const uint32_t dst = base + s_off[min(gtri, n_bins - 1u)] + s_rank[slot];
+            qout.o[dst] = qin.o[i];
+            qout.d[dst] = qin.d[i];
+            qout.T[dst] = qin.T[i];
+            reinterpret_cast<float4*>(hits)[dst] = h;
+        }
+    }
 }
 
 // One bounce of RayTracer::trace after the closest hit is known
 // (orion/raytracer.cpp:116-206).  POINT selects the point-light branch.
+// Input: the `*n_live` vertex records k_extend left (every one of them a hit); the grid is sized
+// for the ray count, blocks past the live count leave at once.
 template <int MODE, bool POINT>
-__global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, uint32_t depth, Queues qin, uint32_t n,
+__global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, uint32_t depth, Queues qin,
+                                                  const unsigned long long* __restrict__ n_live,
                                                   const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
                                                   float4* __restrict__ rad) {
+    const uint32_t n = (uint32_t)*n_live;
+    if (blockIdx.x * kBlock >= n) return;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    bool live = i < n;
+    const bool live = i < n;
     V3 o = splat(0.0f), d = splat(1.0f), T = splat(0.0f);
     uint32_t pid = 0, pixel = 0, sample = 0;
     HitRec h = miss_rec();
@@ -174,7 +237,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
         pid = __float_as_uint(a.w); pixel = __float_as_uint(b.w); sample = __float_as_uint(c.w);
         const float4 hr = reinterpret_cast<const float4*>(hits)[i];
         h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
-        live = h.gtri != kInvalid;   // a miss contributes nothing and ends the path (orion/raytracer.cpp:113-114)
     }
 
     const float bias = 1e-3f;
@@ -283,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
         }
     }
 
-    const uint32_t slot = queue_slot(cont, live, out_count);
+    const uint32_t slot = queue_slot(cont, false, out_count);
     if (cont) {
         qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
         qout.d[slot] = make_float4(next_d.x, next_d.y, next_d.z, __uint_as_float(pixel));
@@ -790,35 +852,37 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             Profiled prof(s, ORION_KERNEL_GENERATE, n);
             hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, F, n, qa, d_rad);
         }
-        Queues qin = qa, qout = qb;
+        // qa: rays waiting for their closest hit; qb + d_hits: the vertices that hit, ready to shade.
+        // counters: [0] vertices k_extend kept, [1] rays k_shade emitted for the next bounce.
+        const uint32_t n_bins = (mode == MODE_WAVE) ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
         for (uint32_t depth = 0; n > 0 && depth <= p->max_depth; depth++) {
+            HIP_TRY(hipMemsetAsync(d_count, 0, 16, s->stream));
             {
                 Profiled prof(s, ORION_KERNEL_CLOSEST_HIT, n);
-                if (mode == MODE_WAVE) hipLaunchKernelGGL(k_extend<MODE_WAVE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, qin, n, d_hits);
-                else hipLaunchKernelGGL(k_extend<MODE_LANE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, qin, n, d_hits);
+                const dim3 g((n + kTile - 1) / kTile), b(kBlock);
+                if (mode == MODE_WAVE) hipLaunchKernelGGL(k_extend<MODE_WAVE>, g, b, 0, s->stream, s->view, qa, n, qb, d_hits, d_count, n_bins);
+                else hipLaunchKernelGGL(k_extend<MODE_LANE>, g, b, 0, s->stream, s->view, qa, n, qb, d_hits, d_count, n_bins);
             }
-            HIP_TRY(hipMemsetAsync(d_count, 0, 8, s->stream));
             {
                 Profiled prof(s, ORION_KERNEL_SHADE, n);
                 const dim3 g(grid_for(n)), b(kBlock);
                 if (mode == MODE_WAVE) {
-                    if (point) hipLaunchKernelGGL((k_shade<MODE_WAVE, true>), g, b, 0, s->stream, s->view, F, depth, qin, n, d_hits, qout, d_count, d_rad);
-                    else hipLaunchKernelGGL((k_shade<MODE_WAVE, false>), g, b, 0, s->stream, s->view, F, depth, qin, n, d_hits, qout, d_count, d_rad);
+                    if (point) hipLaunchKernelGGL((k_shade<MODE_WAVE, true>), g, b, 0, s->stream, s->view, F, depth, qb, d_count, d_hits, qa, d_count + 1, d_rad);
+                    else hipLaunchKernelGGL((k_shade<MODE_WAVE, false>), g, b, 0, s->stream, s->view, F, depth, qb, d_count, d_hits, qa, d_count + 1, d_rad);
                 } else {
-                    if (point) hipLaunchKernelGGL((k_shade<MODE_LANE, true>), g, b, 0, s->stream, s->view, F, depth, qin, n, d_hits, qout, d_count, d_rad);
-                    else hipLaunchKernelGGL((k_shade<MODE_LANE, false>), g, b, 0, s->stream, s->view, F, depth, qin, n, d_hits, qout, d_count, d_rad);
+                    if (point) hipLaunchKernelGGL((k_shade<MODE_LANE, true>), g, b, 0, s->stream, s->view, F, depth, qb, d_count, d_hits, qa, d_count + 1, d_rad);
+                    else hipLaunchKernelGGL((k_shade<MODE_LANE, false>), g, b, 0, s->stream, s->view, F, depth, qb, d_count, d_hits, qa, d_count + 1, d_rad);
                 }
             }
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(s->h_count, d_count, 8, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(s->h_count, d_count, 16, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
-            n = s->h_count[0];
+            n = s->h_count[2];
             if (s->profiling) {   // light-sample / shadow rays traced inside the shade launch
                 const uint64_t per_vertex = point ? p->n_lights : (uint64_t)p->light_samples * s->view.n_emissive;
                 s->stats[ORION_KERNEL_SHADOW].launches++;
-                s->stats[ORION_KERNEL_SHADOW].items += (uint64_t)s->h_count[1] * per_vertex;
+                s->stats[ORION_KERNEL_SHADOW].items += (uint64_t)s->h_count[0] * per_vertex;
             }
-            Queues t = qin; qin = qout; qout = t;
         }
         {
             Profiled prof(s, ORION_KERNEL_RESOLVE, P);
