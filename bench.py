@@ -134,21 +134,38 @@ def main():
     }
     if rank == 0:
         E = sum(1 for m in model.meshes if np.any(model.materials[m.material].emissive != 0))
+        # units per kernel: k_extend processes rays; k_shade processes the vertices that hit
+        vertices = stats["shadow"]["items"] // max(1, LIGHT_SAMPLES * E)
+        units = {"closest_hit": ("k_extend", stats["closest_hit"]["items"], BYTES_PER_RAY),
+                 "shade": ("k_shade", vertices, BYTES_PER_RAY * LIGHT_SAMPLES * E + BYTES_PER_VERTEX_STATE)}
+        pmc = {}
+        try:   # HBM bytes per unit measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (see profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        except OSError:
+            pass
         kern = {}
-        for name, per_item in (("closest_hit", BYTES_PER_RAY),
-                               ("shade", BYTES_PER_RAY * LIGHT_SAMPLES * E + BYTES_PER_VERTEX_STATE)):
-            s = stats[name]
-            if s["launches"]:
-                gbs = s["items"] * per_item / (s["ms"] * 1e-3) / 1e9
-                kern[name] = {"launches": s["launches"], "items": s["items"], "ms": s["ms"],
-                              "avg_launch_ms": s["ms"] / s["launches"], "algorithmic_GBs": gbs}
+        for name, (kname, items, per_item) in units.items():
+            st = stats[name]
+            if st["launches"] and st["ms"] > 0:
+                launches = st["launches"]
+                alg_per_launch = items * per_item / launches
+                avg_ms = st["ms"] / launches
+                kern[kname] = {"launches": launches, "units": items, "ms": st["ms"], "avg_launch_ms": avg_ms,
+                               "algorithmic_bytes_per_unit": per_item, "algorithmic_bytes_per_launch": alg_per_launch,
+                               "algorithmic_GBs": alg_per_launch / (avg_ms * 1e-3) / 1e9}
+                if kname in pmc:
+                    per = pmc[kname]["hbm_read_bytes_per_item"] + pmc[kname]["hbm_write_bytes_per_item"]
+                    kern[kname]["pmc_hbm_bytes_per_launch"] = per * items / launches
         if kern:
             dom = max(kern, key=lambda k: kern[k]["ms"])
-            out["roofline"] = {"bound": "hbm", "kernel": "k_extend" if dom == "closest_hit" else "k_shade",
-                               "achieved": kern[dom]["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": kern[dom]["algorithmic_GBs"] / HBM_PEAK_GBS, "traffic": None}
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["algorithmic_GBs"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": kern[dom]["algorithmic_GBs"] / HBM_PEAK_GBS,
+                               "traffic": kern[dom].get("pmc_hbm_bytes_per_launch"),
+                               "note": "achieved = algorithmic bytes per launch / average launch duration (HIP events on the "
+                                       "library's stream over the timed region); traffic = HBM bytes per launch from the PMC passes "
+                                       "in profiles/ (FETCH_SIZE doubled per the gfx950 correction). The kernel is VALU-issue bound "
+                                       "(about 85-90 % SQ_ACTIVE_INST_VALU), not HBM bound."}
             out["kernels"] = kern
-            # closest-hit queries issued per second: extend rays + the light-sample rays traced inside shade
             rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
             out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
                            "Mrays_per_s_per_gpu": rays / dt / 1e6,

@@ -257,3 +257,53 @@ def test_full_size_properties(gpu):
     near[1:] |= hit[:-1]; near[:-1] |= hit[1:]; near[:, 1:] |= hit[:, :-1]; near[:, :-1] |= hit[:, 1:]
     assert (a[:, :, :3][~near] == 0).all()
     assert a[:, :, :3][hit].mean() > 0
+
+
+def test_render_argument_validation(gpu):
+    sc = scene_for(gpu, "cornell")
+    eye, look, up, yv = CORNELL_CAM
+    cam = gpu.camera_vectors(eye, look, up, yv, 1.0)
+    with pytest.raises(gpu.OrionError, match="light_samples"):
+        sc.render(cam, 8, 8, 0, 1, 0, 2)
+    with pytest.raises(gpu.OrionError, match="spp_end"):
+        sc.render(cam, 8, 8, 2, 1, 1, 2)
+    with pytest.raises(gpu.OrionError, match="tile"):
+        sc.render(cam, 8, 8, 0, 1, 1, 2, tile=(0, 0, 9, 8))
+    with pytest.raises(gpu.OrionError, match="point lights"):
+        sc.render(cam, 8, 8, 0, 1, 1, 2, lights=np.zeros((17, 7), np.float32))
+    with pytest.raises(gpu.OrionError, match="empty image"):
+        sc.render(cam, 0, 8, 0, 1, 1, 2, accum=np.zeros((8, 1, 4), np.float32))
+    # zero samples is a no-op, not an error
+    acc = sc.render(cam, 8, 8, 3, 3, 1, 2)
+    assert (acc == 0).all()
+    with pytest.raises(gpu.OrionError, match="unknown option"):
+        sc.set_option("no_such_option", 1)
+
+
+def test_render_without_any_light(gpu):
+    """No point lights and no emissive mesh: the BRDF branch still bounces, everything stays black
+    (orion/raytracer.cpp:131-194 with an empty emissiveSurfaces())."""
+    from oracle import bindings as ob
+    model = conftest.load_model("view_test")
+    sc = gpu.Scene(model, device=0)
+    cam = gpu.camera_vectors([0, 0, 2], [0, 0, 0], [0, 1, 0], 1.0, 1.0)
+    img = sc.render(cam, 32, 32, 0, 2, 1, 4, seed=1)
+    ref = ob.OracleScene(model).render(cam, 32, 32, 0, 2, 1, 4, seed=1)
+    assert (img[:, :, :3] == 0).all() and (ref[:, :, :3] == 0).all() and (img[:, :, 3] == 2).all()
+    sc.close()
+
+
+def test_many_emissive_meshes_and_odd_light_samples(gpu):
+    """Two emissive meshes, three light samples each: the per-mesh, per-sample accumulation order of
+    orion/raytracer.cpp:133-159."""
+    import copy
+    from oracle import bindings as ob
+    model = copy.deepcopy(conftest.load_model("cornell"))
+    model.materials[model.meshes[5].material].emissive = np.array([0.5, 0.2, 0.1], np.float32)   # the short box glows too
+    sc = gpu.Scene(model, device=0)
+    eye, look, up, yv = CORNELL_CAM
+    cam = gpu.camera_vectors(eye, look, up, yv, 1.0)
+    img = sc.render(cam, 48, 48, 0, 4, 3, 6, seed=3)
+    ref = ob.OracleScene(model).render(cam, 48, 48, 0, 4, 3, 6, seed=3, accum_mode=1)
+    assert psnr(img[:, :, :3], ref[:, :, :3]) > 60.0
+    sc.close()
