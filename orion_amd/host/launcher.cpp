@@ -1,6 +1,6 @@
 // Command-line front end with the reference's flags (orion/launcher.cpp:17-32):
 //   orion_rt <rtc_file> [-o|--output FILE] [-p SPP] [-l LIGHT_SAMPLES] [-t|--threads N]
-// plus --seed and --device.  -t is accepted and ignored.
+// plus --seed, --device and --bvh (split strategy of the host BVH build).  -t is accepted and ignored.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -10,7 +10,7 @@
 
 static void usage(const char* argv0) {
     std::printf("Usage: %s rtc_file [--output,-o FILE=raytracer.png] [-p PIXEL_SAMPLES=1] [-l SHADOW_RAY_SAMPLES=1]\n"
-                "       [--threads,-t N (ignored)] [--seed S=1] [--device D=-1]\n", argv0);
+                "       [--threads,-t N (ignored)] [--seed S=1] [--device D=-1] [--bvh median|middle|sah]\n", argv0);
 }
 
 int main(int argc, char** argv) {
@@ -30,6 +30,13 @@ int main(int argc, char** argv) {
         else if (a == "-t" || a == "--threads") threads = (unsigned)std::strtoul(value("--threads"), nullptr, 10);
         else if (a == "--seed") rt.seed = std::strtoull(value("--seed"), nullptr, 10);
         else if (a == "--device") rt.device = std::atoi(value("--device"));
+        else if (a == "--bvh") {
+            const std::string v = value("--bvh");
+            if (v == "median") rt.bvh_strategy = 0;
+            else if (v == "middle") rt.bvh_strategy = 1;
+            else if (v == "sah") rt.bvh_strategy = 2;
+            else { std::printf("--bvh must be median, middle or sah\n"); return 105; }
+        }
         else if (!a.empty() && a[0] == '-') { std::printf("Unknown option %s\n", a.c_str()); usage(argv[0]); return 109; }
         else if (rtc_file.empty()) rtc_file = a;
         else { std::printf("Unexpected argument %s\n", a.c_str()); usage(argv[0]); return 109; }

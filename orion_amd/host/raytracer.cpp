@@ -118,7 +118,7 @@ void RayTracer::traceRTC(const std::string& rtc_file_name, const std::string& pa
 
     Model model;
     load_obj(parent_dir(rtc_file_name) + "/" + rtc.obj_file, model);
-    build_bvh(model);
+    build_bvh(model, static_cast<SplitStrategy>(bvh_strategy));
     size_t n_emissive = 0;
     for (const Mesh& m : model.meshes) n_emissive += model.materials[m.material].is_emissive();
     std::printf("Number of emissive meshes: %zu\n", n_emissive);

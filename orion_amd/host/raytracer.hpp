@@ -21,6 +21,7 @@ public:
 
     uint64_t seed = 1;   // key of the counter-based generator (the reference seeds from `this`)
     int device = -1;     // HIP device, -1 = current
+    int bvh_strategy = 0; // 0 MEDIAN (the reference's default), 1 MIDDLE, 2 SAH (orion/avx/sbvh.hpp:83-90)
 
     // Radiance image of the last traceRTC call, row-major rgb, already scaled by 1/samples.
     const std::vector<float>& image() const { return image_; }

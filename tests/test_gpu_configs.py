@@ -102,3 +102,27 @@ def test_image_textures_at_scale():
     fr2.rtc = copy.deepcopy(fr.rtc)
     fr2.rtc.recursion_level = 2
     compare(fr2, 256, 144, 4, 1, model=model)
+
+
+def test_c1_matches_the_references_published_render():
+    """End-to-end pin of the bounce loop against the reference's OWN output: its README render of
+    this exact config (images/cornell-box_fhd2.png, reduced 8x8 by tests/golden/make_readme_fixture.py).
+    Our render goes through the reference's PNG quantisation (divide by the image maximum, clamp, x255,
+    truncate -- orion/raytracer.cpp:255-280) and the same 8x8 box filter.  Different random streams and
+    the reference's approximate rsqrt leave noise-level differences only."""
+    from orion_amd import api
+    want = np.load(os.path.join(conftest.GOLDEN, "cornell_readme_ds8.npy"))
+    fr = frame("c1_cornell_brdf_fhd")
+    sc = api.Scene(fr.model, device=0)
+    W, H, SPP = 1920, 1080, 2048
+    acc = sc.render(fr.camera12, W, H, 0, SPP, 2, 100, seed=1)
+    sc.close()
+    img = acc[:, :, :3] * np.float32(1.0 / SPP)
+    inv_scale = np.float32(1.0) / img.max()
+    q = np.floor(np.minimum(np.float32(1.0), img * inv_scale) * 255).astype(np.float32) / 255.0
+    got = q.reshape(135, 8, 240, 8, 3).mean(axis=(1, 3))
+    err = got - want
+    p = 10 * np.log10(1.0 / np.mean(err.astype(np.float64) ** 2))
+    print(f"PSNR against the reference's README render: {p:.2f} dB, mean offset {float(err.mean()):+.5f}, max |err| {float(np.abs(err).max()):.4f}")
+    assert p > 40.0, f"PSNR against the reference's README render: {p:.1f} dB"
+    assert abs(float(err.mean())) < 2e-3, "systematic brightness offset"

@@ -190,3 +190,26 @@ def test_render_modes_agree(models):
     f = sc.render(cam, 24, 24, 0, 4, 2, 6, seed=3, tile=(0, 0, 24, 10))
     f = sc.render(cam, 24, 24, 0, 4, 2, 6, seed=3, tile=(0, 10, 24, 24), accum=f)
     assert np.array_equal(bits(f), bits(b))
+
+
+def test_bounce_loop_against_the_references_published_render(models):
+    """The reference's README render (1920x1080, 2048 spp, depth 100, 2 light samples), box-filtered
+    8x8 to 240x135 (tests/golden/cornell_readme_ds8.npy), against the oracle rendering 240x135 directly:
+    the per-sample jitter spans the whole (larger) pixel, so the expectation is the same box filter.
+    The PNG's normalisation constant (its brightest full-resolution pixel) is fitted."""
+    want = np.load(os.path.join(conftest.GOLDEN, "cornell_readme_ds8.npy")).astype(np.float64)
+    from orion_amd import host
+    r = host.parse_rtc(os.path.join(conftest.ASSETS, "cornell-box.rtc"))
+    W, H, SPP = 240, 135, 384
+    cam = ob.camera_vectors(r.view_point, r.look_at, r.vector_up, r.y_view, W / H)
+    sc = ob.OracleScene(models("cornell"))
+    for kind in (1, 0):   # counter RNG (threads) and the reference's xoroshiro stream (serial, fewer samples)
+        spp = SPP if kind == 1 else 48
+        acc = sc.render(cam, W, H, 0, spp, 2, 100, seed=7, rng_kind=kind, accum_mode=0, threads=8)
+        got = acc[:, :, :3].astype(np.float64) / spp
+        dark = want < 0.98   # saturated pixels of the PNG carry no information
+        a = float((got[dark] * want[dark]).sum() / (got[dark] ** 2).sum())
+        err = np.minimum(1.0, a * got)[dark] - want[dark]
+        p = 10 * np.log10(1.0 / np.mean(err ** 2))
+        assert p > (38.0 if kind == 1 else 33.0), f"rng {kind}: PSNR {p:.1f} dB"
+        assert abs(err.mean()) < 3e-3
