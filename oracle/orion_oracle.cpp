@@ -10,16 +10,16 @@
 // the reference (orion/avx/sbvh.cpp:142-149) and its result is defined by the
 // libstdc++ implementation, so the restatement calls the same library routine.
 //
-// Parity status: PINNED for everything below the bounce loop.  Each routine is
-// checked bit-for-bit (or to 1e-6 where the reference normalises with the
-// hardware-approximate rsqrtps) against the real reference classes compiled
-// from /root/reference by oracle/Makefile into oracle/_ref/ (see
-// tests/test_oracle_vs_ref.py, and the golden vectors it wrote under
-// tests/golden/).  The bounce loop itself (orion/raytracer.cpp:105-210) lives in
-// a translation unit that needs assimp and tqdm, neither of which exists in
-// this image, so it cannot be executed here: that ~100-line glue is restated
-// from the source text and is "parity unpinned" as a whole, although every
-// routine it calls is pinned.
+// Parity status: PINNED.  Each routine below the bounce loop is checked bit-for-bit (or to 1e-6
+// where the reference normalises with the hardware-approximate rsqrtps) against the real
+// reference classes compiled from /root/reference by oracle/Makefile into oracle/_ref/
+// (tests/golden/make_golden.py wrote the vectors, tests/test_oracle_golden.py checks them).
+// The bounce loop itself (orion/raytracer.cpp:105-210) lives in a translation unit that needs
+// assimp and tqdm, neither of which exists in this image, so it cannot be executed here: that
+// ~100-line glue is restated from the source text and pinned end to end against the reference's
+// own published render of the Cornell box (images/cornell-box_fhd2.png, reduced to
+// tests/golden/cornell_readme_ds8.npy), which this file reproduces to noise level with both
+// random generators.
 //
 // Arithmetic contract (all FP32, compiled with -ffp-contract=off so that only
 // the fused operations written out below are fused):
