@@ -31,9 +31,10 @@ struct Tri {
     float v0[3];
     uint32_t gtri;   // scene-wide triangle id = mesh.tri_base + original triangle index
     float e1[3];
-    uint32_t pad0;
+    float light_bias;      // (triangle area / mesh area) * triangle count: the sampling bias of
+                           // TracedMesh::randomPointOnSurface (orion/mesh.hpp:182), a per-triangle constant
     float e2[3];
-    uint32_t pad1;
+    float light_intensity; // light_bias * mesh area (orion/raytracer.cpp:153)
 };
 static_assert(sizeof(Tri) == 48, "Tri layout");
 
@@ -94,6 +95,7 @@ struct FrameParams {
     uint32_t spp_begin;        // absolute index of the batch's first sample
     uint32_t n_samples;        // samples in this batch
     uint32_t light_samples, max_depth;
+    float inv_light_samples;   // 1.0f / light_samples (orion/raytracer.cpp:158)
     uint32_t seed_lo, seed_hi;
     uint32_t n_lights;
     Light lights[kMaxLights];

@@ -12,6 +12,8 @@
 // Every kernel is built twice: with the per-lane traversal and with the
 // wave-synchronous (scalar-load) traversal of intersect.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
 
 #include <cmath>
 #include <cstdio>
@@ -143,11 +145,12 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, uint32_t n_p
     rad[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-#ifndef ORION_RAYS_PER_THREAD
-#define ORION_RAYS_PER_THREAD 4
-#endif
-constexpr uint32_t kRaysPerThread = ORION_RAYS_PER_THREAD;
-constexpr uint32_t kTile = kBlock * kRaysPerThread;   // rays per block
+// Rays per thread of k_extend: kRaysWide while the queue is long (larger tiles group better and
+// amortise the block's bookkeeping), 1 once a bounce no longer fills the machine, where the
+// launch time is one thread's serial work and more blocks are the only way to shorten it.
+constexpr uint32_t kRaysWide = 4;
+constexpr uint32_t kTileWide = kBlock * kRaysWide;
+constexpr uint32_t kNarrowBelow = 1u << 21;   // rays; about one ray per thread slot of the chip x 4
 constexpr uint32_t kMaxBins = 64;
 
 // Closest hit of every queued ray (orion/model.hpp:52-62).  Rays that miss end here: a miss
@@ -158,15 +161,44 @@ constexpr uint32_t kMaxBins = 64;
 // on the same surface: its light-sample rays start on one plane and aim at one light, so the
 // wave-synchronous traversal's early exits hold for whole waves, and its material fetches are
 // uniform.  n_bins = number of triangle bins (<= kMaxBins; larger ids share the last bin), 1 = no grouping.
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues qin, uint32_t n, Queues qout, HitRec* __restrict__ hits,
-                                                   unsigned long long* __restrict__ counter, uint32_t n_bins) {
+// The ray count is read on the device (prev[1], written by the previous bounce's shade launch;
+// prev == null: n_bound itself): the host sizes the grid from an older, larger count (n_bound)
+// and never has to wait for the exact one.  `clear` is a counter slot of a later bounce, zeroed
+// here.  The previous bounce's counters are final by now; one lane stores them to the host's
+// pinned mirror (`publish`), where the host polls for them.  Each count travels with the tag in
+// one 64-bit store, so the host needs no ordering between the two (and the kernel no fence,
+// which at system scope would write back and invalidate the L2).
+__device__ __forceinline__ void publish_counters(const unsigned long long* cnt, unsigned long long* publish, uint32_t tag) {
+    const unsigned long long hi = (unsigned long long)tag << 32;
+    __hip_atomic_store(publish, hi | (uint32_t)cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(publish + 1, hi | (uint32_t)cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_publish(const unsigned long long* cnt, unsigned long long* publish, uint32_t tag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) publish_counters(cnt, publish, tag);
+}
+
+template <int MODE, uint32_t kRaysPerThread>
+__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
+                                                   Queues qout, HitRec* __restrict__ hits, unsigned long long* __restrict__ counter,
+                                                   unsigned long long* __restrict__ clear, unsigned long long* publish, uint32_t tag, uint32_t n_bins) {
+    constexpr uint32_t kTile = kBlock * kRaysPerThread;   // rays per block
     __shared__ float4 s_hit[kTile];
     __shared__ uint16_t s_rank[kTile];
     __shared__ uint32_t s_cnt[kMaxBins];
     __shared__ uint32_t s_off[kMaxBins];
     __shared__ uint32_t s_base;
     const uint32_t tile0 = blockIdx.x * kTile;
+    uint32_t n = n_bound;
+    if (prev) { const unsigned long long m = prev[1]; if (m < n) n = (uint32_t)m; }
+    // Block 0's housekeeping stores come after the traversal on purpose: a store ahead of the
+    // scene loads would keep the compiler from issuing them as scalar loads.
+    auto housekeeping = [&]() {
+        if (blockIdx.x != 0) return;
+        if (threadIdx.x < 2) clear[threadIdx.x] = 0ull;
+        if (prev && threadIdx.x == 0) publish_counters(prev, publish, tag);
+    };
+    if (tile0 >= n) { housekeeping(); return; }
     if (threadIdx.x < kMaxBins) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t k = 0; k < kRaysPerThread; k++) {
@@ -213,6 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues qin, uint
             reinterpret_cast<float4*>(hits)[dst] = h;
         }
     }
+    housekeeping();
 }
 
 // One bounce of RayTracer::trace after the closest hit is known
@@ -263,17 +296,17 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
         // Direct light: light_samples points on every emissive mesh (orion/raytracer.cpp:133-159)
         V3 kd = splat(0.0f);
         if (live) kd = tex_fetch(S, S.meshes[mesh_id].tex[kTexDiffuse], tu, tv);
-        const float inv_ls = 1.0f / (float)F.light_samples;
+        const float inv_ls = F.inv_light_samples;
         for (uint32_t e = 0; e < S.n_emissive; e++) {
             const uint32_t lmesh = S.emissive[e];
             const Mesh lm = S.meshes[lmesh];
             V3 contrib = splat(0.0f);
             for (uint32_t l = 0; l < F.light_samples; l++) {
                 V3 target = splat(0.0f), sd = splat(1.0f);
-                float lbias = 0.0f;
+                float lint = 0.0f;
                 if (live) {
                     const Words4 r = philox4x32_10(pixel, sample, depth, e * F.light_samples + l, F.seed_lo, F.seed_hi);
-                    light_point(S, lm, r, target, lbias);
+                    light_point(S, lm, r, target, lint);
                     sd = target - hitPos;
                 }
                 HitRec h2 = miss_rec();
@@ -282,7 +315,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
                     const Surface s2 = surface_at(S, h2.gtri, h2.u, h2.v);
                     if (s2.mesh == lmesh) {   // the sample is visible iff the closest hit is the light itself
                         const V3 lcol = tex_fetch(S, lm.tex[kTexEmissive], s2.tu, s2.tv);
-                        const float lint = lbias * lm.area;
                         contrib = contrib + color_brdf(kd, normal, hitPos, target, lcol, lint, normalize(s2.normal));
                     }
                 }
@@ -403,6 +435,11 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; int kernel; uint64_t items; };
 
+// Bounce-counter ring: the host launches bounce d while it reads the counters of bounce d - kLag,
+// so the stream always holds queued work and no launch waits on a host round trip.
+constexpr uint32_t kRing = 8, kLag = 2, kClearAhead = 3;
+static_assert(kLag + kClearAhead + 1 < kRing, "a slot must be read before it is cleared for reuse");
+
 } // namespace
 
 struct OrionScene {
@@ -418,7 +455,11 @@ struct OrionScene {
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
     DevBuf q[6], hits, rad, counter;
-    uint32_t* h_count = nullptr;      // pinned
+    // Per-bounce counters travel to the host through a ring: the device slot of bounce d is
+    // d % kRing; the next bounce's extend launch stores it into the pinned mirror
+    // {tag << 32 | vertices, tag << 32 | rays}.
+    unsigned long long* h_count = nullptr;   // pinned and coherent, kRing x 2 words
+    uint32_t tag = 0;                 // last tag handed out; a tag is used once per scene
     // profiling
     bool profiling = false;
     std::vector<EventPair> pending;
@@ -436,25 +477,25 @@ struct OrionScene {
 
 namespace {
 
-struct Profiled {
-    OrionScene* s; int kernel; uint64_t items; EventPair ev{}; bool on;
-    Profiled(OrionScene* s_, int k, uint64_t it) : s(s_), kernel(k), items(it), on(s_->profiling) {
-        if (!on) return;
-        auto take = [&]() {
-            hipEvent_t e;
-            if (!s->pool.empty()) { e = s->pool.back(); s->pool.pop_back(); }
-            else (void)hipEventCreate(&e);
-            return e;
-        };
-        ev.a = take(); ev.b = take(); ev.kernel = kernel; ev.items = items;
-        (void)hipEventRecord(ev.a, s->stream);
+// Launch on the scene's stream.  With profiling on, the launch carries a start and a stop event
+// bound to the kernel's own dispatch (no extra packets in the stream), so the recorded time is the
+// kernel's execution time and the stream runs as it does unprofiled.
+template <typename... KArgs, typename... Args>
+void launch(OrionScene* s, int kernel_id, uint64_t items, void (*kernel)(KArgs...), dim3 grid, dim3 block, Args&&... args) {
+    if (!s->profiling) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, s->stream, static_cast<KArgs>(args)...);
+        return;
     }
-    ~Profiled() {
-        if (!on) return;
-        (void)hipEventRecord(ev.b, s->stream);
-        s->pending.push_back(ev);
-    }
-};
+    auto take = [&]() {
+        hipEvent_t e;
+        if (!s->pool.empty()) { e = s->pool.back(); s->pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    EventPair ev{take(), take(), kernel_id, items};
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, s->stream, ev.a, ev.b, 0, static_cast<KArgs>(args)...);
+    s->pending.push_back(ev);
+}
 
 void drain_profile(OrionScene* s) {
     for (EventPair& p : s->pending) {
@@ -535,22 +576,36 @@ struct Flattener {
     }
 };
 
+// Waits until the device has stored both counters of a bounce under `tag` into their pinned slot.
+// The wait is a poll of host memory; it gives up when the stream has drained (or failed) without
+// the tag turning up.
+int await_counters(OrionScene* s, const unsigned long long* slot, uint32_t tag, uint32_t out[2]) {
+    const volatile unsigned long long* v = slot;
+    for (uint64_t spin = 0;; spin++) {
+        const unsigned long long a = v[0], b = v[1];
+        if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) { out[0] = (uint32_t)a; out[1] = (uint32_t)b; return 0; }
+        for (int k = 0; k < 32; k++) __builtin_ia32_pause();   // poll gently: the device's store has to win the line
+        if ((spin & 0x3FF) == 0x3FF) {
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return fail(2, std::string("bounce loop: ") + hipGetErrorString(q));
+            const unsigned long long a2 = v[0], b2 = v[1];   // the stream is idle: every store has landed
+            if ((uint32_t)(a2 >> 32) == tag && (uint32_t)(b2 >> 32) == tag) { out[0] = (uint32_t)a2; out[1] = (uint32_t)b2; return 0; }
+            return fail(2, "bounce loop: counters were not published");
+        }
+    }
+}
+
 int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_out) {
-    Profiled prof(s, ORION_KERNEL_CLOSEST_HIT, n);
-    if (s->mode() == MODE_WAVE)
-        hipLaunchKernelGGL(k_closest_api<MODE_WAVE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
-    else
-        hipLaunchKernelGGL(k_closest_api<MODE_LANE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
+    launch(s, ORION_KERNEL_CLOSEST_HIT, n, s->mode() == MODE_WAVE ? k_closest_api<MODE_WAVE> : k_closest_api<MODE_LANE>,
+           dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_anyhit(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, uint8_t* d_out) {
-    Profiled prof(s, ORION_KERNEL_ANY_HIT, n);
-    if (s->mode() == MODE_WAVE)
-        hipLaunchKernelGGL(k_anyhit_api<MODE_WAVE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
-    else
-        hipLaunchKernelGGL(k_anyhit_api<MODE_LANE>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
+    launch(s, ORION_KERNEL_ANY_HIT, n, s->mode() == MODE_WAVE ? k_anyhit_api<MODE_WAVE> : k_anyhit_api<MODE_LANE>,
+           dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -667,6 +722,13 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
             H3 e1 = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, e2 = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
             area += std::fabs(hdot(e1, e2)) * 0.5f;   // orion/geometry.hpp:155-157, orion/mesh.hpp:197-208
         }
+        for (uint32_t i = 0; i < ntri; i++) {   // per-triangle light-sampling constants, now that the area is known
+            Tri& t = tris[slot_base + i];
+            const H3 e1 = {t.e1[0], t.e1[1], t.e1[2]}, e2 = {t.e2[0], t.e2[1], t.e2[2]};
+            const float tri_area = std::fabs(hdot(e1, e2)) * 0.5f;
+            t.light_bias = (tri_area / area) * (float)ntri;
+            t.light_intensity = t.light_bias * area;
+        }
         Mesh& dm = dmeshes[mi];
         dm.tri_base = tri_base; dm.n_tri = ntri;
         dm.tex[0] = md.tex_ambient; dm.tex[1] = md.tex_diffuse; dm.tex[2] = md.tex_specular; dm.tex[3] = md.tex_emissive;
@@ -703,7 +765,8 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     s->device = device;
     auto bail = [&](int rc) { orion_hip_scene_destroy(s); return rc; };
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { s->stream = nullptr; return bail(fail(2, "hipStreamCreate failed")); }
-    if (hipHostMalloc((void**)&s->h_count, 64, hipHostMallocDefault) != hipSuccess) { s->h_count = nullptr; return bail(fail(2, "hipHostMalloc failed")); }
+    if (hipHostMalloc((void**)&s->h_count, kRing * 16, hipHostMallocCoherent) != hipSuccess) { s->h_count = nullptr; return bail(fail(2, "hipHostMalloc failed")); }
+    std::memset(s->h_count, 0, kRing * 16);
     SceneView& v = s->view;
     int rc = 0;
     if ((rc = upload(s, nodes, &v.nodes))) return bail(rc);
@@ -814,6 +877,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     F.width = p->width; F.height = p->height;
     F.tile_x0 = x0; F.tile_y0 = y0; F.tile_w = x1 - x0; F.tile_h = y1 - y0;
     F.light_samples = p->light_samples; F.max_depth = p->max_depth;
+    F.inv_light_samples = 1.0f / (float)p->light_samples;
     F.seed_lo = (uint32_t)p->seed; F.seed_hi = (uint32_t)(p->seed >> 32);
     F.n_lights = p->n_lights;
     for (uint32_t i = 0; i < p->n_lights; i++) std::memcpy(&F.lights[i], &p->lights[i], sizeof(Light));
@@ -836,58 +900,77 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     for (DevBuf& b : s->q) if (int rc = b.reserve(max_paths * 16)) return rc;
     if (int rc = s->hits.reserve(max_paths * 16)) return rc;
     if (int rc = s->rad.reserve(max_paths * 16)) return rc;
-    if (int rc = s->counter.reserve(64)) return rc;
+    if (int rc = s->counter.reserve(kRing * 16)) return rc;
     unsigned long long* d_count = static_cast<unsigned long long*>(s->counter.p);
     Queues qa{static_cast<float4*>(s->q[0].p), static_cast<float4*>(s->q[1].p), static_cast<float4*>(s->q[2].p)};
     Queues qb{static_cast<float4*>(s->q[3].p), static_cast<float4*>(s->q[4].p), static_cast<float4*>(s->q[5].p)};
     HitRec* d_hits = static_cast<HitRec*>(s->hits.p);
     float4* d_rad = static_cast<float4*>(s->rad.p);
     const int mode = s->mode();
+    const uint64_t rays_per_vertex = point ? p->n_lights : (uint64_t)p->light_samples * s->view.n_emissive;
 
     for (uint64_t sb = p->spp_begin; sb < p->spp_end; sb += per_batch) {
         const uint32_t ns = (uint32_t)((p->spp_end - sb < per_batch) ? (p->spp_end - sb) : per_batch);
         F.spp_begin = (uint32_t)sb; F.n_samples = ns;
-        uint32_t n = (uint32_t)(P * ns);
-        {
-            Profiled prof(s, ORION_KERNEL_GENERATE, n);
-            hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, F, n, qa, d_rad);
-        }
+        const uint32_t n0 = (uint32_t)(P * ns);
+        HIP_TRY(hipMemsetAsync(d_count, 0, kRing * 16, s->stream));
+        launch(s, ORION_KERNEL_GENERATE, n0, k_generate, dim3(grid_for(n0)), dim3(kBlock), F, n0, qa, d_rad);
         // qa: rays waiting for their closest hit; qb + d_hits: the vertices that hit, ready to shade.
-        // counters: [0] vertices k_extend kept, [1] rays k_shade emitted for the next bounce.
+        // Counter slot of bounce d (two 64-bit words at d % kRing): [0] vertices k_extend kept,
+        // [1] rays k_shade emitted for bounce d + 1.  The kernels read their counts on the device;
+        // the host only needs an upper bound to size the grids and the zero that ends the loop, and
+        // takes both from the bounce kLag launches back.
         const uint32_t n_bins = (mode == MODE_WAVE) ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
-        for (uint32_t depth = 0; n > 0 && depth <= p->max_depth; depth++) {
-            HIP_TRY(hipMemsetAsync(d_count, 0, 16, s->stream));
-            {
-                Profiled prof(s, ORION_KERNEL_CLOSEST_HIT, n);
-                const dim3 g((n + kTile - 1) / kTile), b(kBlock);
-                if (mode == MODE_WAVE) hipLaunchKernelGGL(k_extend<MODE_WAVE>, g, b, 0, s->stream, s->view, qa, n, qb, d_hits, d_count, n_bins);
-                else hipLaunchKernelGGL(k_extend<MODE_LANE>, g, b, 0, s->stream, s->view, qa, n, qb, d_hits, d_count, n_bins);
+        uint32_t bound = n0;          // >= the number of rays entering the next bounce to launch
+        uint32_t consumed = 0;        // bounces whose counters the host has read
+        uint32_t launched = 0;
+        uint64_t rays_in = n0;        // rays that entered bounce `consumed`
+        uint32_t tags[kRing] = {};
+        auto consume = [&]() -> int { // read the counters of bounce `consumed`
+            const uint32_t slot = consumed % kRing;
+            uint32_t h[2];
+            if (int rc = await_counters(s, s->h_count + 2 * slot, tags[slot], h)) return rc;
+            if (s->profiling) {
+                s->stats[ORION_KERNEL_CLOSEST_HIT].items += rays_in;
+                s->stats[ORION_KERNEL_SHADE].items += h[0];
+                s->stats[ORION_KERNEL_SHADOW].launches++;   // light-sample / shadow rays traced inside the shade launch
+                s->stats[ORION_KERNEL_SHADOW].items += (uint64_t)h[0] * rays_per_vertex;
             }
-            {
-                Profiled prof(s, ORION_KERNEL_SHADE, n);
-                const dim3 g(grid_for(n)), b(kBlock);
-                if (mode == MODE_WAVE) {
-                    if (point) hipLaunchKernelGGL((k_shade<MODE_WAVE, true>), g, b, 0, s->stream, s->view, F, depth, qb, d_count, d_hits, qa, d_count + 1, d_rad);
-                    else hipLaunchKernelGGL((k_shade<MODE_WAVE, false>), g, b, 0, s->stream, s->view, F, depth, qb, d_count, d_hits, qa, d_count + 1, d_rad);
-                } else {
-                    if (point) hipLaunchKernelGGL((k_shade<MODE_LANE, true>), g, b, 0, s->stream, s->view, F, depth, qb, d_count, d_hits, qa, d_count + 1, d_rad);
-                    else hipLaunchKernelGGL((k_shade<MODE_LANE, false>), g, b, 0, s->stream, s->view, F, depth, qb, d_count, d_hits, qa, d_count + 1, d_rad);
-                }
-            }
+            rays_in = h[1];
+            consumed++;
+            return 0;
+        };
+        for (uint32_t depth = 0; depth <= p->max_depth; depth++) {
+            const uint32_t slot = depth % kRing, prev_slot = (depth + kRing - 1) % kRing;
+            unsigned long long* cnt = d_count + 2 * slot;
+            const unsigned long long* prev = depth ? d_count + 2 * prev_slot : nullptr;
+            unsigned long long* clear = d_count + 2 * ((depth + kClearAhead) % kRing);
+            tags[slot] = ++s->tag;     // bounce `depth` is published under this tag by the next extend launch
+            const bool wide = bound >= kNarrowBelow;
+            const uint32_t tile = wide ? kTileWide : kBlock;
+            launch(s, ORION_KERNEL_CLOSEST_HIT, 0,
+                   mode == MODE_WAVE ? (wide ? k_extend<MODE_WAVE, kRaysWide> : k_extend<MODE_WAVE, 1>)
+                                     : (wide ? k_extend<MODE_LANE, kRaysWide> : k_extend<MODE_LANE, 1>),
+                   dim3((bound + tile - 1) / tile), dim3(kBlock), s->view, qa, prev, bound, qb, d_hits, cnt, clear,
+                   s->h_count + 2 * prev_slot, tags[prev_slot], n_bins);
+            launch(s, ORION_KERNEL_SHADE, 0,
+                   mode == MODE_WAVE ? (point ? k_shade<MODE_WAVE, true> : k_shade<MODE_WAVE, false>)
+                                     : (point ? k_shade<MODE_LANE, true> : k_shade<MODE_LANE, false>),
+                   dim3(grid_for(bound)), dim3(kBlock), s->view, F, depth, qb, cnt, d_hits, qa, cnt + 1, d_rad);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(s->h_count, d_count, 16, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
-            n = s->h_count[2];
-            if (s->profiling) {   // light-sample / shadow rays traced inside the shade launch
-                const uint64_t per_vertex = point ? p->n_lights : (uint64_t)p->light_samples * s->view.n_emissive;
-                s->stats[ORION_KERNEL_SHADOW].launches++;
-                s->stats[ORION_KERNEL_SHADOW].items += (uint64_t)s->h_count[0] * per_vertex;
+            launched = depth + 1;
+            if (depth >= kLag) {
+                if (int rc = consume()) return rc;
+                if (rays_in == 0) break;          // bounce `consumed` has no rays; the ones launched past it find none either
+                bound = (uint32_t)rays_in;
             }
         }
-        {
-            Profiled prof(s, ORION_KERNEL_RESOLVE, P);
-            hipLaunchKernelGGL(k_resolve, dim3(grid_for(P)), dim3(kBlock), 0, s->stream, F, d_rad, d_accum);
+        if (s->profiling) {   // the statistics want every bounce; the last one has no extend launch after it
+            const uint32_t last = (launched - 1) % kRing;
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s->stream, d_count + 2 * last, s->h_count + 2 * last, tags[last]);
+            while (consumed < launched) if (int rc = consume()) return rc;
         }
+        launch(s, ORION_KERNEL_RESOLVE, P, k_resolve, dim3(grid_for(P)), dim3(kBlock), F, d_rad, d_accum);
         HIP_TRY(hipGetLastError());
     }
     if (!accum_dev) HIP_TRY(hipMemcpyAsync(accum_any, d_accum, img_bytes, hipMemcpyDeviceToHost, s->stream));

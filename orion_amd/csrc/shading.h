@@ -135,15 +135,17 @@ __device__ __forceinline__ V3 color_phong(V3 ka, V3 kd, V3 ks, float shininess, 
 
 // TracedMesh::randomPointOnSurface + Triangle::randomPointOnSurface
 // (orion/mesh.hpp:179-184, orion/geometry.hpp:160-171), draws taken from one Philox block.
-__device__ __forceinline__ void light_point(const SceneView& S, const Mesh& lm, Words4 r, V3& point, float& bias) {
+// bias = (triangle area / mesh area) * triangle count and intensity = bias * mesh area
+// (orion/raytracer.cpp:153) depend on the picked triangle only; the scene upload computes them
+// once per triangle with the same FP32 operations.
+__device__ __forceinline__ void light_point(const SceneView& S, const Mesh& lm, Words4 r, V3& point, float& intensity) {
     // x % n without the division when n is a power of two (same value)
     const uint32_t ri = (lm.n_tri & (lm.n_tri - 1u)) == 0u ? (r.w[0] & (lm.n_tri - 1u)) : (r.w[0] % lm.n_tri);
     const uint32_t slot = S.slot_of[lm.tri_base + ri];
     const float4* tp = reinterpret_cast<const float4*>(S.tris + slot);
     const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
     const V3 v0 = mk(T0.x, T0.y, T0.z), e1 = mk(T1.x, T1.y, T1.z), e2 = mk(T2.x, T2.y, T2.z);
-    const float tri_area = fabsf(dot(e1, e2)) * 0.5f;
-    bias = (tri_area / lm.area) * (float)lm.n_tri;
+    intensity = T2.w;
     float a = u01(r.w[1]);
     float b = u01(r.w[2]);
     if (a + b > 1) { a = 1.0f - a; b = 1.0f - b; }
