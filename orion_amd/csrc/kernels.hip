@@ -126,9 +126,8 @@ __device__ __forceinline__ void path_pixel(const FrameParams& F, uint32_t pid, u
     sample = F.spp_begin + k;
 }
 
-__global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, uint32_t n_paths, Queues q, float4* __restrict__ rad) {
-    const uint32_t pid = blockIdx.x * kBlock + threadIdx.x;
-    if (pid >= n_paths) return;
+// Primary ray of path `pid` as its three queue records (orion/raytracer.cpp:53-72).
+__device__ __forceinline__ void primary_ray(const FrameParams& F, uint32_t pid, float4& qo, float4& qd, float4& qT) {
     uint32_t pixel, sample, px, py;
     path_pixel(F, pid, pixel, sample, px, py);
     // per-sample jitter shared by all pixels (orion/raytracer.cpp:53-63)
@@ -139,10 +138,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, uint32_t n_p
     const float y = 2 * ((float)py / (float)F.height) - 1;
     const float xs = x + jx, ys = -(y + jy);
     const V3 dir = (ld3(F.front) + ld3(F.right) * xs) + ld3(F.up) * ys;
-    q.o[pid] = make_float4(F.eye[0], F.eye[1], F.eye[2], __uint_as_float(pid));
-    q.d[pid] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pixel));
-    q.T[pid] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
-    rad[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    qo = make_float4(F.eye[0], F.eye[1], F.eye[2], __uint_as_float(pid));
+    qd = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pixel));
+    qT = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
 }
 
 // Rays per thread of k_extend: kRaysWide while the queue is long (larger tiles group better and
@@ -178,8 +176,12 @@ __global__ void k_publish(const unsigned long long* cnt, unsigned long long* pub
     if (blockIdx.x == 0 && threadIdx.x == 0) publish_counters(cnt, publish, tag);
 }
 
-template <int MODE, uint32_t kRaysPerThread>
-__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
+// GEN: the first bounce.  The rays are the primary rays, computed here from the path index
+// instead of being read from a queue (no generate pass, no 64 B/path round trip through HBM), and
+// every path's radiance slot is zeroed.
+template <int MODE, uint32_t kRaysPerThread, bool GEN>
+__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, float4* __restrict__ rad,
+                                                   Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
                                                    Queues qout, HitRec* __restrict__ hits, unsigned long long* __restrict__ counter,
                                                    unsigned long long* __restrict__ clear, unsigned long long* publish, uint32_t tag, uint32_t n_bins) {
     constexpr uint32_t kTile = kBlock * kRaysPerThread;   // rays per block
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues qin, cons
         const bool active = i < n;
         V3 o = splat(0.0f), d = splat(1.0f);
         if (active) {
-            const float4 a = qin.o[i], b = qin.d[i];
+            float4 a, b, c;
+            if (GEN) primary_ray(F, i, a, b, c);
+            else { a = qin.o[i]; b = qin.d[i]; }
             o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
         }
         HitRec h = miss_rec();
@@ -239,11 +243,15 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, Queues qin, cons
         if (gtri != kInvalid) {
             const uint32_t i = tile0 + slot;
             const uint32_t dst = base + s_off[min(gtri, n_bins - 1u)] + s_rank[slot];
-            qout.o[dst] = qin.o[i];
-            qout.d[dst] = qin.d[i];
-            qout.T[dst] = qin.T[i];
+            float4 a, b, c;
+            if (GEN) primary_ray(F, i, a, b, c);
+            else { a = qin.o[i]; b = qin.d[i]; c = qin.T[i]; }
+            qout.o[dst] = a;
+            qout.d[dst] = b;
+            qout.T[dst] = c;
             reinterpret_cast<float4*>(hits)[dst] = h;
         }
+        if (GEN && tile0 + slot < n) rad[tile0 + slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     housekeeping();
 }
@@ -914,7 +922,6 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         F.spp_begin = (uint32_t)sb; F.n_samples = ns;
         const uint32_t n0 = (uint32_t)(P * ns);
         HIP_TRY(hipMemsetAsync(d_count, 0, kRing * 16, s->stream));
-        launch(s, ORION_KERNEL_GENERATE, n0, k_generate, dim3(grid_for(n0)), dim3(kBlock), F, n0, qa, d_rad);
         // qa: rays waiting for their closest hit; qb + d_hits: the vertices that hit, ready to shade.
         // Counter slot of bounce d (two 64-bit words at d % kRing): [0] vertices k_extend kept,
         // [1] rays k_shade emitted for bounce d + 1.  The kernels read their counts on the device;
@@ -948,11 +955,17 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             tags[slot] = ++s->tag;     // bounce `depth` is published under this tag by the next extend launch
             const bool wide = bound >= kNarrowBelow;
             const uint32_t tile = wide ? kTileWide : kBlock;
-            launch(s, ORION_KERNEL_CLOSEST_HIT, 0,
-                   mode == MODE_WAVE ? (wide ? k_extend<MODE_WAVE, kRaysWide> : k_extend<MODE_WAVE, 1>)
-                                     : (wide ? k_extend<MODE_LANE, kRaysWide> : k_extend<MODE_LANE, 1>),
-                   dim3((bound + tile - 1) / tile), dim3(kBlock), s->view, qa, prev, bound, qb, d_hits, cnt, clear,
-                   s->h_count + 2 * prev_slot, tags[prev_slot], n_bins);
+            auto extend = [&](auto kernel) {
+                launch(s, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((bound + tile - 1) / tile), dim3(kBlock), s->view, F, d_rad, qa,
+                       prev, bound, qb, d_hits, cnt, clear, s->h_count + 2 * prev_slot, tags[prev_slot], n_bins);
+            };
+            if (depth == 0) {   // primary rays are generated inside the launch
+                if (mode == MODE_WAVE) { if (wide) extend(k_extend<MODE_WAVE, kRaysWide, true>); else extend(k_extend<MODE_WAVE, 1, true>); }
+                else { if (wide) extend(k_extend<MODE_LANE, kRaysWide, true>); else extend(k_extend<MODE_LANE, 1, true>); }
+            } else {
+                if (mode == MODE_WAVE) { if (wide) extend(k_extend<MODE_WAVE, kRaysWide, false>); else extend(k_extend<MODE_WAVE, 1, false>); }
+                else { if (wide) extend(k_extend<MODE_LANE, kRaysWide, false>); else extend(k_extend<MODE_LANE, 1, false>); }
+            }
             launch(s, ORION_KERNEL_SHADE, 0,
                    mode == MODE_WAVE ? (point ? k_shade<MODE_WAVE, true> : k_shade<MODE_WAVE, false>)
                                      : (point ? k_shade<MODE_LANE, true> : k_shade<MODE_LANE, false>),
