@@ -66,6 +66,34 @@ __device__ __forceinline__ bool slab_hit(float lox, float loy, float loz, float 
     return (tmax > tmin) && (tmax > 0.0f);
 }
 
+// The same test on v_min/v_max.  For operands that are not NaN, (a<b)?a:b and min(a,b) differ at
+// most in the sign of a zero, which the two final comparisons cannot see, so the result is the
+// same bit.  NaN operands (0 * inf: the origin on a slab plane of an axis the ray does not move
+// along) are where the select order matters; slab_safe() tells whether a ray can produce one.
+// Single-instruction min/max: the builtins would first canonicalise every operand (v_max x, x).
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+__device__ __forceinline__ bool slab_hit_fast(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 inv) {
+    float t1x = (lox - o.x) * inv.x, t1y = (loy - o.y) * inv.y, t1z = (loz - o.z) * inv.z;
+    float t2x = (hix - o.x) * inv.x, t2y = (hiy - o.y) * inv.y, t2z = (hiz - o.z) * inv.z;
+    float tmin = vmax3(vmin(t1x, t2x), vmin(t1y, t2y), vmin(t1z, t2z));
+    float tmax = vmin3(vmax(t1x, t2x), vmax(t1y, t2y), vmax(t1z, t2z));
+    return (tmax > tmin) && (tmax > 0.0f);
+}
+
+// True when no slab product of this ray can be NaN, whatever the (non-NaN) box: the origin is
+// finite and every reciprocal is finite and non-zero, so (bound - o) * inv is finite or +-inf.
+__device__ __forceinline__ bool slab_safe(V3 o, V3 inv) {
+    const float big = __builtin_inff();
+    const bool o_ok = fabsf(o.x) < big && fabsf(o.y) < big && fabsf(o.z) < big;
+    const bool i_ok = fabsf(inv.x) < big && fabsf(inv.y) < big && fabsf(inv.z) < big &&
+                      inv.x != 0.0f && inv.y != 0.0f && inv.z != 0.0f;
+    return o_ok && i_ok;
+}
+
 // Triangle::intersect (orion/geometry.hpp:80-136).  Updates h on acceptance.
 __device__ __forceinline__ bool tri_hit(V3 v0, V3 e1, V3 e2, uint32_t gtri, V3 o, V3 d, HitRec& h) {
     const float eps = 0.000001f;
@@ -105,6 +133,7 @@ __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]);
 template <bool ANY>
 __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, HitRec& h) {
     const V3 inv = ray_inverse(d);
+    const bool fast = __all(slab_safe(o, inv));   // wave-uniform choice of the slab arithmetic
     uint32_t node = 0;
     const uint32_t n_nodes = S.n_nodes;
     while (node < n_nodes) {
@@ -121,7 +150,8 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
             }
             node++;
         } else {
-            node = slab_hit(A.x, A.y, A.z, B.x, B.y, B.z, o, inv) ? node + 1 : a;
+            const bool in = fast ? slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv) : slab_hit(A.x, A.y, A.z, B.x, B.y, B.z, o, inv);
+            node = in ? node + 1 : a;
         }
     }
 }
@@ -138,31 +168,39 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
 template <bool ANY>
 __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
     const V3 inv = ray_inverse(d);
+    const bool fast = __all(!active || slab_safe(o, inv));   // wave-uniform choice of the slab arithmetic
     uint32_t next = active ? 0u : kInvalid;
     const uint32_t n_nodes = S.n_nodes;
     for (uint32_t node = 0; node < n_nodes; node++) {
-        const bool mine = (next == node);
+        const uint32_t un = __builtin_amdgcn_readfirstlane(node);   // the walk is wave-uniform: keep it in SGPRs
+        const bool mine = (next == un);
         if (__ballot(mine) == 0ull) {
-            if (!__any(next != kInvalid)) break;
+            if (ANY && !__any(next != kInvalid)) break;   // every lane has its answer
             continue;
         }
-        const uint32_t un = __builtin_amdgcn_readfirstlane(node);
         const Node N = S.nodes[un];
+        uint32_t to = un + 1;
         if (N.b & kLeafFlag) {
-            const uint32_t cnt = N.b & ~kLeafFlag;
+            const Tri* tp = S.tris + N.a;
+            const Tri* const te = tp + (N.b & ~kLeafFlag);
             bool done = false;
-            for (uint32_t s = 0; s < cnt; s++) {
-                const Tri T = S.tris[N.a + s];
+            for (; tp != te; tp++) {
+                const Tri T = *tp;
+                // The lanes that are not at this node sit the test out (execution mask), so its
+                // early exits fire as soon as the few lanes that are here have failed.
                 if (mine && !(ANY && done)) {
                     bool acc = tri_hit(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.e1[0], T.e1[1], T.e1[2]),
                                        mk(T.e2[0], T.e2[1], T.e2[2]), T.gtri, o, d, h);
                     if (ANY && acc) done = true;
                 }
             }
-            if (mine) next = (ANY && done) ? kInvalid : node + 1;
+            if (ANY && done) to = kInvalid;
         } else {
-            if (mine) next = slab_hit(N.lo[0], N.lo[1], N.lo[2], N.hi[0], N.hi[1], N.hi[2], o, inv) ? node + 1 : N.a;
+            const bool in = fast ? slab_hit_fast(N.lo[0], N.lo[1], N.lo[2], N.hi[0], N.hi[1], N.hi[2], o, inv)
+                                 : slab_hit(N.lo[0], N.lo[1], N.lo[2], N.hi[0], N.hi[1], N.hi[2], o, inv);
+            if (!in) to = N.a;
         }
+        next = mine ? to : next;
     }
 }
 

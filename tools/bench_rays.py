@@ -57,6 +57,11 @@ def main():
                 order = np.argsort(key, kind="stable")
                 batches["R4 binned"] = (o4[order], d4[order])
                 batches["R2 binned"] = (o2[perm][order], d2[perm][order])
+                # ... and inside each surface by direction octant
+                dd = d2[perm]
+                octant = (dd[:, 0] > 0).astype(np.int64) | ((dd[:, 1] > 0).astype(np.int64) << 1) | ((dd[:, 2] > 0).astype(np.int64) << 2)
+                order8 = np.argsort(key * 8 + octant, kind="stable")
+                batches["R2 bin+oct"] = (o2[perm][order8], d2[perm][order8])
         for mode, tag in ((1, "lane"), (2, "wave")):
             if tag == "wave" and model.n_triangles > 2000:
                 continue
