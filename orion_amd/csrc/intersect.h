@@ -165,12 +165,18 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
 // paths, which for scenes of a few dozen nodes is close to every lane's own path.
 // Must be entered by all lanes that want a result; `active` = false lanes idle.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next);
+
 template <bool ANY>
 __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
     const V3 inv = ray_inverse(d);
     const bool fast = __all(!active || slab_safe(o, inv));   // wave-uniform choice of the slab arithmetic
     uint32_t next = active ? 0u : kInvalid;
     const uint32_t n_nodes = S.n_nodes;
+    if (!ANY && fast && n_nodes) {   // the common case runs the hand-scheduled loop
+        traverse_wave_closest_asm(S, o, d, inv, h, next);
+        return;
+    }
     for (uint32_t node = 0; node < n_nodes; node++) {
         const uint32_t un = __builtin_amdgcn_readfirstlane(node);   // the walk is wave-uniform: keep it in SGPRs
         const bool mine = (next == un);
@@ -202,6 +208,193 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
         }
         next = mine ? to : next;
     }
+}
+
+// ---------------------------------------------------------------------------
+// The closest-hit wave walk, hand-scheduled.  Same algorithm and the same FP32
+// operations in the same order as traverse_wave<false> with slab_hit_fast and
+// tri_hit (the division is the compiler's own correctly rounded sequence), but
+// with what the compiler will not do for this loop: one scalar pointer that
+// steps through the node array, one 48-byte scalar fetch per triangle, the
+// execution mask narrowed stage by stage with a single restore per triangle,
+// and no register shuffling between loop levels.  The wave spends its time in
+// this loop, one instruction at a time, so its length is the traversal's speed.
+// Preconditions: slab_safe() holds for every active lane (the caller checks it
+// wave-wide), n_nodes > 0 and the scene's triangle array is below 4 GiB (the
+// walk is only chosen for scenes of a few dozen nodes).  SGPRs s64-s75 hold the
+// node or triangle being processed.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next) {
+    float ht = h.t, hu = h.u, hv = h.v;
+    uint32_t hg = h.gtri;
+    // VGPR temporaries; the division's five share registers with values that are not live yet
+    float px, py, pz, det, idet, tx, ty, tz, qx, qy, qz, aa, bb, cc, uu, du, dv, ww, dt;
+    // SGPR temporaries: EX = lanes that entered, MI = lanes at the current node, PM = a stage's verdict
+    unsigned long long EX, MI, PM;
+    uint32_t noff, toff, cnt, node, node1, eps;
+    asm volatile(
+        "s_mov_b64 %[EX], exec\n"
+        "s_mov_b32 %[noff], 0\n"                       // byte offset of the node, steps by 32
+        "s_mov_b32 %[node], 0\n"
+        "s_mov_b32 %[eps], 0x358637bd\n"               // 1e-6f
+        "L_node%=:\n"
+        "v_cmp_eq_u32_e64 %[MI], %[node], %[nx]\n"
+        "s_cmp_eq_u64 %[MI], 0\n"
+        "s_cbranch_scc1 L_next%=\n"
+        "s_load_dwordx8 s[64:71], %[nodes], %[noff]\n" // lo.xyz a | hi.xyz b
+        "s_add_u32 %[node1], %[node], 1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "s_bitcmp1_b32 s71, 31\n"
+        "s_cbranch_scc1 L_leaf%=\n"
+        // ---- inner node: slab test, next = in ? node + 1 : skip
+        "v_sub_f32 %[aa], s64, %[ox]\n"
+        "v_sub_f32 %[bb], s68, %[ox]\n"
+        "v_sub_f32 %[cc], s65, %[oy]\n"
+        "v_sub_f32 %[uu], s69, %[oy]\n"
+        "v_sub_f32 %[du], s66, %[oz]\n"
+        "v_sub_f32 %[dv], s70, %[oz]\n"
+        "v_mul_f32 %[aa], %[aa], %[ix]\n"
+        "v_mul_f32 %[bb], %[bb], %[ix]\n"
+        "v_mul_f32 %[cc], %[cc], %[iy]\n"
+        "v_mul_f32 %[uu], %[uu], %[iy]\n"
+        "v_mul_f32 %[du], %[du], %[iz]\n"
+        "v_mul_f32 %[dv], %[dv], %[iz]\n"
+        "v_min_f32 %[tx], %[aa], %[bb]\n"
+        "v_min_f32 %[ty], %[cc], %[uu]\n"
+        "v_min_f32 %[tz], %[du], %[dv]\n"
+        "v_max_f32 %[aa], %[aa], %[bb]\n"
+        "v_max_f32 %[cc], %[cc], %[uu]\n"
+        "v_max_f32 %[du], %[du], %[dv]\n"
+        "v_max3_f32 %[tx], %[tx], %[ty], %[tz]\n"      // tmin
+        "v_min3_f32 %[aa], %[aa], %[cc], %[du]\n"      // tmax
+        "v_cmp_gt_f32 vcc, %[aa], %[tx]\n"
+        "v_cmp_lt_f32_e64 %[PM], 0, %[aa]\n"
+        "v_mov_b32 %[bb], %[node1]\n"
+        "v_mov_b32 %[cc], s67\n"
+        "s_and_b64 vcc, vcc, %[PM]\n"
+        "v_cndmask_b32_e32 %[bb], %[cc], %[bb], vcc\n"
+        "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"
+        "s_branch L_next%=\n"
+        // ---- leaf: its triangles, for the lanes that are here
+        "L_leaf%=:\n"
+        "s_and_b32 %[cnt], s71, 0x7fffffff\n"          // triangle count
+        "s_cbranch_scc0 L_leaf_done%=\n"
+        "s_mul_i32 %[toff], s67, 48\n"                 // byte offset of the leaf's first triangle
+        "s_and_b64 exec, %[EX], %[MI]\n"
+        "L_tri%=:\n"
+        "s_load_dwordx4 s[64:67], %[tris], %[toff]\n"              // v0.xyz gtri
+        "s_load_dwordx4 s[68:71], %[tris], %[toff] offset:0x10\n"  // e1.xyz
+        "s_load_dwordx4 s[72:75], %[tris], %[toff] offset:0x20\n"  // e2.xyz
+        "s_add_u32 %[toff], %[toff], 48\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        // pvec = cross(d, e2)
+        "v_mul_f32 %[px], s74, %[dy]\n"
+        "v_mul_f32 %[py], s72, %[dz]\n"
+        "v_mul_f32 %[pz], s73, %[dx]\n"
+        "v_fma_f32 %[px], -%[dz], s73, %[px]\n"
+        "v_fma_f32 %[py], -%[dx], s74, %[py]\n"
+        "v_fma_f32 %[pz], -%[dy], s72, %[pz]\n"
+        // det = dot(e1, pvec)
+        "v_mul_f32 %[aa], s68, %[px]\n"
+        "v_mul_f32 %[bb], s69, %[py]\n"
+        "v_mul_f32 %[cc], s70, %[pz]\n"
+        "v_add_f32 %[aa], %[aa], %[bb]\n"
+        "v_add_f32 %[det], %[aa], %[cc]\n"
+        "v_cmp_nlt_f32_e64 %[PM], |%[det]|, %[eps]\n"
+        "s_and_b64 exec, exec, %[PM]\n"
+        "s_cbranch_scc0 L_tri_next%=\n"
+        // inv_det = 1 / det, correctly rounded (q0 = qx, r = qy, q1 = qz, e = ww, m = dt)
+        "v_div_scale_f32 %[qx], %[PM], %[det], %[det], 1.0\n"
+        "v_rcp_f32 %[qy], %[qx]\n"
+        "v_div_scale_f32 %[qz], vcc, 1.0, %[det], 1.0\n"
+        "v_fma_f32 %[ww], -%[qx], %[qy], 1.0\n"
+        "v_fmac_f32 %[qy], %[ww], %[qy]\n"
+        "v_mul_f32 %[dt], %[qz], %[qy]\n"
+        "v_fma_f32 %[ww], -%[qx], %[dt], %[qz]\n"
+        "v_fmac_f32 %[dt], %[ww], %[qy]\n"
+        "v_fma_f32 %[qx], -%[qx], %[dt], %[qz]\n"
+        "v_div_fmas_f32 %[qx], %[qx], %[qy], %[dt]\n"
+        "v_div_fixup_f32 %[idet], %[qx], %[det], 1.0\n"
+        // tvec = o - v0, u = dot(tvec, pvec) * inv_det
+        "v_subrev_f32 %[tx], s64, %[ox]\n"
+        "v_subrev_f32 %[ty], s65, %[oy]\n"
+        "v_subrev_f32 %[tz], s66, %[oz]\n"
+        "v_mul_f32 %[aa], %[tx], %[px]\n"
+        "v_mul_f32 %[bb], %[ty], %[py]\n"
+        "v_mul_f32 %[cc], %[tz], %[pz]\n"
+        "v_add_f32 %[aa], %[aa], %[bb]\n"
+        "v_add_f32 %[du], %[aa], %[cc]\n"
+        "v_mul_f32 %[uu], %[du], %[idet]\n"
+        "v_cmp_ngt_f32 vcc, 0, %[uu]\n"
+        "v_cmp_nlt_f32_e64 %[PM], 1.0, %[uu]\n"
+        "s_and_b64 %[PM], vcc, %[PM]\n"
+        "s_and_b64 exec, exec, %[PM]\n"
+        "s_cbranch_scc0 L_tri_next%=\n"
+        // qvec = cross(tvec, e1), v = dot(d, qvec) * inv_det
+        "v_mul_f32 %[qx], s70, %[ty]\n"
+        "v_mul_f32 %[qy], s68, %[tz]\n"
+        "v_mul_f32 %[qz], s69, %[tx]\n"
+        "v_fma_f32 %[qx], -%[tz], s69, %[qx]\n"
+        "v_fma_f32 %[qy], -%[tx], s70, %[qy]\n"
+        "v_fma_f32 %[qz], -%[ty], s68, %[qz]\n"
+        "v_mul_f32 %[aa], %[dx], %[qx]\n"
+        "v_mul_f32 %[bb], %[dy], %[qy]\n"
+        "v_mul_f32 %[cc], %[dz], %[qz]\n"
+        "v_add_f32 %[aa], %[aa], %[bb]\n"
+        "v_add_f32 %[dv], %[aa], %[cc]\n"
+        "v_mul_f32 %[ww], %[dv], %[idet]\n"
+        "v_cmp_ngt_f32 vcc, 0, %[ww]\n"
+        "v_add_f32 %[bb], %[uu], %[ww]\n"
+        "v_cmp_nlt_f32_e64 %[PM], 1.0, %[bb]\n"
+        "s_and_b64 %[PM], vcc, %[PM]\n"
+        "s_and_b64 exec, exec, %[PM]\n"
+        "s_cbranch_scc0 L_tri_next%=\n"
+        // t = dot(e2, qvec) * inv_det
+        "v_mul_f32 %[aa], s72, %[qx]\n"
+        "v_mul_f32 %[bb], s73, %[qy]\n"
+        "v_mul_f32 %[cc], s74, %[qz]\n"
+        "v_add_f32 %[aa], %[aa], %[bb]\n"
+        "v_add_f32 %[dt], %[aa], %[cc]\n"
+        "v_mul_f32 %[bb], %[dt], %[idet]\n"
+        "v_cmp_ngt_f32 vcc, %[bb], %[ht]\n"
+        "v_cmp_ngt_f32_e64 %[PM], 0, %[bb]\n"
+        "s_and_b64 %[PM], vcc, %[PM]\n"
+        "s_and_b64 exec, exec, %[PM]\n"
+        "s_cbranch_scc0 L_tri_next%=\n"
+        // accepted: the +0.0f lane of the reference's dot products, then the record
+        "v_add_f32 %[aa], 0, %[du]\n"
+        "v_add_f32 %[cc], 0, %[dv]\n"
+        "v_add_f32 %[bb], 0, %[dt]\n"
+        "v_mul_f32 %[hu], %[aa], %[idet]\n"
+        "v_mul_f32 %[hv], %[cc], %[idet]\n"
+        "v_mul_f32 %[ht], %[bb], %[idet]\n"
+        "v_mov_b32 %[hg], s67\n"
+        "L_tri_next%=:\n"
+        "s_and_b64 exec, %[EX], %[MI]\n"
+        "s_sub_u32 %[cnt], %[cnt], 1\n"
+        "s_cmp_lg_u32 %[cnt], 0\n"
+        "s_cbranch_scc1 L_tri%=\n"
+        "L_leaf_done%=:\n"
+        "s_mov_b64 exec, %[EX]\n"
+        "v_mov_b32 %[bb], %[node1]\n"
+        "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"
+        "L_next%=:\n"
+        "s_add_u32 %[noff], %[noff], 32\n"
+        "s_add_u32 %[node], %[node], 1\n"
+        "s_cmp_lt_u32 %[node], %[nn]\n"
+        "s_cbranch_scc1 L_node%=\n"
+        "s_mov_b64 exec, %[EX]\n"
+        : [nx] "+v"(next), [ht] "+v"(ht), [hu] "+v"(hu), [hv] "+v"(hv), [hg] "+v"(hg),
+          [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [det] "=&v"(det), [idet] "=&v"(idet),
+          [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz), [qx] "=&v"(qx), [qy] "=&v"(qy), [qz] "=&v"(qz),
+          [aa] "=&v"(aa), [bb] "=&v"(bb), [cc] "=&v"(cc), [uu] "=&v"(uu), [du] "=&v"(du), [dv] "=&v"(dv), [ww] "=&v"(ww), [dt] "=&v"(dt),
+          [EX] "=&s"(EX), [MI] "=&s"(MI), [PM] "=&s"(PM),
+          [noff] "=&s"(noff), [toff] "=&s"(toff), [cnt] "=&s"(cnt), [node] "=&s"(node), [node1] "=&s"(node1), [eps] "=&s"(eps)
+        : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z),
+          [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z),
+          [nodes] "s"(S.nodes), [tris] "s"(S.tris), [nn] "s"(S.n_nodes)
+        : "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "vcc", "scc");
+    h.t = ht; h.u = hu; h.v = hv; h.gtri = hg;
 }
 
 } // namespace orion_dev
