@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 outputs (kernel stats CSV + PMC counter_collection CSVs) into a small
-per-kernel text summary for profiles/.  Usage: summarize_profile.py <gpurun_out prefix> <out.md>"""
+per-kernel text summary for profiles/.  Usage: summarize_profile.py <gpurun_out prefix> <out.md> [traffic.json]
+With a third argument also writes the HBM bytes per ray / per shaded vertex that bench.py reports
+as roofline.traffic (needs the run's bench.json for the unit counts)."""
 import collections
 import csv
 import glob
@@ -19,7 +21,7 @@ def kname(n):
 def main():
     prefix, out = sys.argv[1], sys.argv[2]
     lines = []
-    trace = glob.glob(prefix + "trace/*kernel_stats.csv")
+    trace = glob.glob(prefix + "trace/**/*kernel_stats.csv", recursive=True)
     if trace:
         lines.append("## rocprofv3 --kernel-trace --stats (kernel, calls, total ms, average us, % of GPU time)\n")
         for r in csv.DictReader(open(trace[0])):
@@ -31,7 +33,7 @@ def main():
                          ", ".join(f"{k} {v['ms']:.3f} ms / {v['launches']} launches" for k, v in d.get("kernels", {}).items()))
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.Counter()
-    for f in glob.glob(prefix + "*/p_counter_collection.csv"):
+    for f in glob.glob(prefix + "pmc*/**/*counter_collection.csv", recursive=True):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = kname(r["Kernel_Name"])
@@ -59,6 +61,20 @@ def main():
                 lines.append(f"- per wave: {v['SQ_INSTS_VALU'] / v['SQ_WAVES']:.0f} VALU, {v['SQ_INSTS_SALU'] / v['SQ_WAVES']:.0f} SALU, {v['SQ_INSTS_SMEM'] / v['SQ_WAVES']:.0f} SMEM instructions; "
                              f"waiting share SQ_WAIT_ANY/SQ_WAVE_CYCLES = {v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.2f}")
             lines.append("")
+    if len(sys.argv) > 3 and os.path.exists(prefix + "trace/bench.json"):
+        d = json.load(open(prefix + "trace/bench.json"))
+        # The counter passes run the same command as the traced one, and the counters also see the
+        # warm-up steps, which bench.py's unit counts leave out.
+        scale = (d["steps"] + d["warmup"]) / d["steps"]
+        units = {"k_extend": d["kernels"]["k_extend"]["units"] * scale, "k_shade": d["kernels"]["k_shade"]["units"] * scale}
+        note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 2 --warmup 1; FETCH_SIZE doubled "
+                "(gfx950 counts half the bytes of wide coalesced reads); item = ray for k_extend, shaded vertex for k_shade")
+        traffic = {}
+        for k, n in units.items():
+            if k in agg and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k] and n:
+                traffic[k] = {"hbm_read_bytes_per_item": agg[k]["FETCH_SIZE"] * 1024 * 2 / n,
+                              "hbm_write_bytes_per_item": agg[k]["WRITE_SIZE"] * 1024 / n, "items": n, "note": note}
+        json.dump(traffic, open(sys.argv[3], "w"), indent=1)
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
