@@ -227,8 +227,8 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next) {
     float ht = h.t, hu = h.u, hv = h.v;
     uint32_t hg = h.gtri;
-    // VGPR temporaries; the division's five share registers with values that are not live yet
-    float px, py, pz, det, idet, tx, ty, tz, qx, qy, qz, aa, bb, cc, uu, du, dv, ww, dt;
+    // VGPR temporaries; the division's five and qvec share registers with values that are dead or not live yet
+    float px, py, pz, det, idet, tx, ty, tz, aa, bb, cc, uu, du, dv, ww, dt;
     // SGPR temporaries: EX = lanes that entered, MI = lanes at the current node, PM = a stage's verdict
     unsigned long long EX, MI, PM;
     uint32_t noff, toff, cnt, node, node1, eps;
@@ -303,18 +303,18 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_cmp_nlt_f32_e64 %[PM], |%[det]|, %[eps]\n"
         "s_and_b64 exec, exec, %[PM]\n"
         "s_cbranch_scc0 L_tri_next%=\n"
-        // inv_det = 1 / det, correctly rounded (q0 = qx, r = qy, q1 = qz, e = ww, m = dt)
-        "v_div_scale_f32 %[qx], %[PM], %[det], %[det], 1.0\n"
-        "v_rcp_f32 %[qy], %[qx]\n"
-        "v_div_scale_f32 %[qz], vcc, 1.0, %[det], 1.0\n"
-        "v_fma_f32 %[ww], -%[qx], %[qy], 1.0\n"
-        "v_fmac_f32 %[qy], %[ww], %[qy]\n"
-        "v_mul_f32 %[dt], %[qz], %[qy]\n"
-        "v_fma_f32 %[ww], -%[qx], %[dt], %[qz]\n"
-        "v_fmac_f32 %[dt], %[ww], %[qy]\n"
-        "v_fma_f32 %[qx], -%[qx], %[dt], %[qz]\n"
-        "v_div_fmas_f32 %[qx], %[qx], %[qy], %[dt]\n"
-        "v_div_fixup_f32 %[idet], %[qx], %[det], 1.0\n"
+        // inv_det = 1 / det, correctly rounded (q0 = aa, r = bb, q1 = cc, e = ww, m = dt)
+        "v_div_scale_f32 %[aa], %[PM], %[det], %[det], 1.0\n"
+        "v_rcp_f32 %[bb], %[aa]\n"
+        "v_div_scale_f32 %[cc], vcc, 1.0, %[det], 1.0\n"
+        "v_fma_f32 %[ww], -%[aa], %[bb], 1.0\n"
+        "v_fmac_f32 %[bb], %[ww], %[bb]\n"
+        "v_mul_f32 %[dt], %[cc], %[bb]\n"
+        "v_fma_f32 %[ww], -%[aa], %[dt], %[cc]\n"
+        "v_fmac_f32 %[dt], %[ww], %[bb]\n"
+        "v_fma_f32 %[aa], -%[aa], %[dt], %[cc]\n"
+        "v_div_fmas_f32 %[aa], %[aa], %[bb], %[dt]\n"
+        "v_div_fixup_f32 %[idet], %[aa], %[det], 1.0\n"
         // tvec = o - v0, u = dot(tvec, pvec) * inv_det
         "v_subrev_f32 %[tx], s64, %[ox]\n"
         "v_subrev_f32 %[ty], s65, %[oy]\n"
@@ -330,16 +330,16 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "s_and_b64 %[PM], vcc, %[PM]\n"
         "s_and_b64 exec, exec, %[PM]\n"
         "s_cbranch_scc0 L_tri_next%=\n"
-        // qvec = cross(tvec, e1), v = dot(d, qvec) * inv_det
-        "v_mul_f32 %[qx], s70, %[ty]\n"
-        "v_mul_f32 %[qy], s68, %[tz]\n"
-        "v_mul_f32 %[qz], s69, %[tx]\n"
-        "v_fma_f32 %[qx], -%[tz], s69, %[qx]\n"
-        "v_fma_f32 %[qy], -%[tx], s70, %[qy]\n"
-        "v_fma_f32 %[qz], -%[ty], s68, %[qz]\n"
-        "v_mul_f32 %[aa], %[dx], %[qx]\n"
-        "v_mul_f32 %[bb], %[dy], %[qy]\n"
-        "v_mul_f32 %[cc], %[dz], %[qz]\n"
+        // qvec = cross(tvec, e1) (in pvec's registers), v = dot(d, qvec) * inv_det
+        "v_mul_f32 %[px], s70, %[ty]\n"
+        "v_mul_f32 %[py], s68, %[tz]\n"
+        "v_mul_f32 %[pz], s69, %[tx]\n"
+        "v_fma_f32 %[px], -%[tz], s69, %[px]\n"
+        "v_fma_f32 %[py], -%[tx], s70, %[py]\n"
+        "v_fma_f32 %[pz], -%[ty], s68, %[pz]\n"
+        "v_mul_f32 %[aa], %[dx], %[px]\n"
+        "v_mul_f32 %[bb], %[dy], %[py]\n"
+        "v_mul_f32 %[cc], %[dz], %[pz]\n"
         "v_add_f32 %[aa], %[aa], %[bb]\n"
         "v_add_f32 %[dv], %[aa], %[cc]\n"
         "v_mul_f32 %[ww], %[dv], %[idet]\n"
@@ -350,9 +350,9 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "s_and_b64 exec, exec, %[PM]\n"
         "s_cbranch_scc0 L_tri_next%=\n"
         // t = dot(e2, qvec) * inv_det
-        "v_mul_f32 %[aa], s72, %[qx]\n"
-        "v_mul_f32 %[bb], s73, %[qy]\n"
-        "v_mul_f32 %[cc], s74, %[qz]\n"
+        "v_mul_f32 %[aa], s72, %[px]\n"
+        "v_mul_f32 %[bb], s73, %[py]\n"
+        "v_mul_f32 %[cc], s74, %[pz]\n"
         "v_add_f32 %[aa], %[aa], %[bb]\n"
         "v_add_f32 %[dt], %[aa], %[cc]\n"
         "v_mul_f32 %[bb], %[dt], %[idet]\n"
@@ -386,7 +386,7 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "s_mov_b64 exec, %[EX]\n"
         : [nx] "+v"(next), [ht] "+v"(ht), [hu] "+v"(hu), [hv] "+v"(hv), [hg] "+v"(hg),
           [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [det] "=&v"(det), [idet] "=&v"(idet),
-          [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz), [qx] "=&v"(qx), [qy] "=&v"(qy), [qz] "=&v"(qz),
+          [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz),
           [aa] "=&v"(aa), [bb] "=&v"(bb), [cc] "=&v"(cc), [uu] "=&v"(uu), [du] "=&v"(du), [dv] "=&v"(dv), [ww] "=&v"(ww), [dt] "=&v"(dt),
           [EX] "=&s"(EX), [MI] "=&s"(MI), [PM] "=&s"(PM),
           [noff] "=&s"(noff), [toff] "=&s"(toff), [cnt] "=&s"(cnt), [node] "=&s"(node), [node1] "=&s"(node1), [eps] "=&s"(eps)
