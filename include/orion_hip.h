@@ -169,6 +169,8 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *   "traversal"   0 = choose per scene (default), 1 = per-lane traversal,
  *                 2 = wave-synchronous traversal (scene data through scalar loads)
  *   "batch_paths" upper bound on paths in flight per render batch
+ *   "hand_scheduled" 1 (default) = the wave-synchronous closest-hit walk runs its
+ *                 hand-scheduled form, 0 = the compiler's form of the same loop
  * Results never depend on these. */
 int orion_hip_scene_set_option(OrionScene* scene, const char* name, int64_t value);
 

@@ -78,6 +78,7 @@ struct SceneView {
     uint32_t n_tris;
     uint32_t n_meshes;
     uint32_t n_emissive;
+    uint32_t hand_scheduled;      // 1: wave-synchronous closest hit through traverse_wave_closest_asm
 };
 
 // Closest-hit record kept in the queues: 16 bytes.  gtri == kInvalid is a miss.

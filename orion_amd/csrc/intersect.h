@@ -173,7 +173,7 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
     const bool fast = __all(!active || slab_safe(o, inv));   // wave-uniform choice of the slab arithmetic
     uint32_t next = active ? 0u : kInvalid;
     const uint32_t n_nodes = S.n_nodes;
-    if (!ANY && fast && n_nodes) {   // the common case runs the hand-scheduled loop
+    if (!ANY && fast && n_nodes && S.hand_scheduled) {   // the common case runs the hand-scheduled loop
         traverse_wave_closest_asm(S, o, d, inv, h, next);
         return;
     }

@@ -788,6 +788,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     if ((rc = upload(s, emissive, &v.emissive))) return bail(rc);
     v.n_nodes = (uint32_t)nodes.size(); v.n_tris = (uint32_t)tris.size();
     v.n_meshes = n_meshes; v.n_emissive = (uint32_t)emissive.size();
+    v.hand_scheduled = 1;
     s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
     for (const Mesh& dm : dmeshes) s->mesh_tri_base.push_back(dm.tri_base);
     *out = s;
@@ -815,6 +816,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
     if (!std::strcmp(name, "traversal")) {
         if (value < 0 || value > 2) return fail(1, "set_option: traversal must be 0, 1 or 2");
         s->traversal = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "hand_scheduled")) {
+        if (value < 0 || value > 1) return fail(1, "set_option: hand_scheduled must be 0 or 1");
+        s->view.hand_scheduled = (uint32_t)value;
         return 0;
     }
     if (!std::strcmp(name, "batch_paths")) {

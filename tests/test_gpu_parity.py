@@ -307,3 +307,33 @@ def test_many_emissive_meshes_and_odd_light_samples(gpu):
     ref = ob.OracleScene(model).render(cam, 48, 48, 0, 4, 3, 6, seed=3, accum_mode=1)
     assert psnr(img[:, :, :3], ref[:, :, :3]) > 60.0
     sc.close()
+
+
+def test_hand_scheduled_walk_equals_the_compilers(gpu):
+    """The wave-synchronous closest-hit walk exists twice: hand-scheduled assembly and the C++ loop it
+    was derived from.  Same rays in, the same bits out -- ray queries and a rendered image."""
+    import torch
+    model = conftest.load_model("cornell")
+    sc = gpu.Scene(model, device=0)
+    sc.set_option("traversal", 2)
+    rng = np.random.default_rng(77)
+    n = 1 << 18
+    o = rng.uniform(-1.2, 1.2, (n, 3)).astype(np.float32) + np.float32([0, 1, 0])
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[::97, 0] = 0.0            # rays that push their wave onto the exact-select slab test
+    o[::1013] = np.float32([0.0, 1.0, 8.0])
+    eye, look, up, yv = CORNELL_CAM
+    cam = gpu.camera_vectors(eye, look, up, yv, 1.5)
+    out = {}
+    for flag in (1, 0):
+        sc.set_option("hand_scheduled", flag)
+        h = sc.closest_hit(o, d)
+        img = sc.render(cam, 96, 64, 0, 6, 2, 20, seed=3)
+        out[flag] = (h.copy(), img.copy())
+    sc.close()
+    a, b = out[1], out[0]
+    assert np.array_equal(a[0]["mesh"], b[0]["mesh"]) and np.array_equal(a[0]["tri"], b[0]["tri"])
+    for f in ("t", "u", "v"):
+        assert np.array_equal(bits(a[0][f]), bits(b[0][f])), f
+    assert (a[0]["mesh"] != gpu.INVALID).sum() > n // 2
+    assert np.array_equal(bits(a[1]), bits(b[1]))

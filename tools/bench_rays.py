@@ -57,6 +57,15 @@ def main():
                 order = np.argsort(key, kind="stable")
                 batches["R4 binned"] = (o4[order], d4[order])
                 batches["R2 binned"] = (o2[perm][order], d2[perm][order])
+                # grouped inside tiles of 1024 consecutive rays only, as k_extend does it: by triangle,
+                # and by triangle + quadrant of the barycentrics (a finer spatial key)
+                uvq = tuv[hit][:, 1:3]
+                uvq = np.tile(uvq, (rep, 1))[:n][perm]
+                quad = (uvq[:, 0] > 0.25).astype(np.int64) * 2 + (uvq[:, 1] > 0.25).astype(np.int64)
+                tile = np.arange(n) // 1024
+                for nm, k2 in (("R4 tile tri", key), ("R4 tile tri+q", key * 4 + quad)):
+                    o_t = np.lexsort((k2, tile))
+                    batches[nm] = (o4[o_t], d4[o_t])
                 # ... and inside each surface by direction octant
                 dd = d2[perm]
                 octant = (dd[:, 0] > 0).astype(np.int64) | ((dd[:, 1] > 0).astype(np.int64) << 1) | ((dd[:, 2] > 0).astype(np.int64) << 2)

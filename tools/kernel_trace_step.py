@@ -1,8 +1,11 @@
+"""Per-launch durations and gaps of the last render batch in a rocprofv3 --kernel-trace CSV.
+Usage: kernel_trace_step.py <trace output directory>"""
 import csv,sys,glob
 f=glob.glob(sys.argv[1]+'/*/*_kernel_trace.csv')[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'k_generate' in r['Kernel_Name']]
+# a batch starts with the extend launch that generates its primary rays (third template argument true)
+idx=[i for i,r in enumerate(rows) if 'k_extend' in r['Kernel_Name'] and 'true>' in r['Kernel_Name']]
 i0=idx[-1]
 prev_end=None
 tot={}
