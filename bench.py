@@ -38,21 +38,29 @@ BYTES_PER_VERTEX_STATE = 96
 
 def cpu_baseline(model, cam, target_s=12.0):
     """Time the oracle (CPU restatement, OpenMP over pixels) on a scaled-down frame of the same scene,
-    camera, depth and light samples; returns samples/s on this host's cores."""
+    camera, depth and light samples; returns samples/s on this host's cores, the same on one
+    thread, and the work counters (box and triangle tests per pixel-sample) of the algorithm."""
     from oracle import bindings as ob
     sc = ob.OracleScene(model)
     threads = min(ob.oracle_lib().oracle_max_threads(), len(os.sched_getaffinity(0)))
     w, h = 480, 270
     t0 = time.time()
-    sc.render(cam, w, h, 0, 4, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=threads)
+    _, counters = sc.render(cam, w, h, 0, 4, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=threads, count=True)
     probe = time.time() - t0
     rate = w * h * 4 / max(probe, 1e-6)
     spp = int(max(4, min(8192, target_s * rate / (w * h))))
     t0 = time.time()
     sc.render(cam, w, h, 0, spp, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=threads)
     dt = time.time() - t0
-    return {"value": w * h * spp / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{w}x{h} x {spp} spp of the same Cornell frame (depth {MAX_DEPTH}, {LIGHT_SAMPLES} light samples), {dt:.1f} s"}
+    multi = w * h * spp / dt
+    spp1 = int(max(1, 3.0 * multi / threads / (w * h)))     # about 3 s on one thread
+    t0 = time.time()
+    sc.render(cam, w, h, 0, spp1, LIGHT_SAMPLES, MAX_DEPTH, seed=1, threads=1)
+    dt1 = time.time() - t0
+    return {"value": multi, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{w}x{h} x {spp} spp of the same Cornell frame (depth {MAX_DEPTH}, {LIGHT_SAMPLES} light samples), {dt:.1f} s",
+            "one_thread_samples_per_s": w * h * spp1 / dt1,
+            "box_tests_per_sample": float(counters[0]) / (w * h * 4), "triangle_tests_per_sample": float(counters[1]) / (w * h * 4)}
 
 
 def main():
@@ -178,7 +186,12 @@ def main():
                            "Mrays_per_s_per_gpu": rays / dt / 1e6,
                            "note": "closest-hit queries traced by rank 0 over the timed region / wall time"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, cam)
+            out["cpu_baseline"] = cb = cpu_baseline(model, cam)
+            if "rays" in out:   # the algorithm's work per closest-hit query (reference counters: orion/avx/sbvh.cpp:8-12)
+                rays_per_sample = (out["rays"]["extend_rays"] + out["rays"]["light_sample_rays"]) / (W * H * spp * args.steps)
+                out["rays"]["per_sample"] = rays_per_sample
+                out["rays"]["box_tests_per_ray"] = cb["box_tests_per_sample"] / rays_per_sample
+                out["rays"]["triangle_tests_per_ray"] = cb["triangle_tests_per_sample"] / rays_per_sample
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:
