@@ -178,8 +178,9 @@ def main():
                                "traffic": kern[dom].get("pmc_hbm_bytes_per_launch"),
                                "note": "achieved = algorithmic bytes per launch / average launch duration (HIP events on the "
                                        "library's stream over the timed region); traffic = HBM bytes per launch from the PMC passes "
-                                       "in profiles/ (FETCH_SIZE doubled per the gfx950 correction). The kernel is VALU-issue bound "
-                                       "(about 85-90 % SQ_ACTIVE_INST_VALU), not HBM bound."}
+                                       "in profiles/ (FETCH_SIZE doubled per the gfx950 correction). The kernel is bound by "
+                                       "instruction issue (one instruction per ~3 cycles per SIMD, the chip's measured "
+                                       "sustained rate), not by HBM."}
             out["kernels"] = kern
             rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
             out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
