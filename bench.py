@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=32)
     ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
+    ap.add_argument("--tail-paths", type=int, default=-1, help="override the library's tail hand-over threshold (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not collect per-kernel HIP-event timings")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -101,6 +102,8 @@ def main():
     cam = api.camera_vectors(eye, look, up, yv, W / H)
     scene = api.Scene(model, device=local)
     scene.set_option("traversal", args.traversal)
+    if args.tail_paths >= 0:
+        scene.set_option("tail_paths", args.tail_paths)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     spp = args.spp_per_step
 

@@ -121,10 +121,11 @@ typedef struct OrionRenderParams {
 #define ORION_KERNEL_SHADOW      1   /* light-sample / shadow rays: traced inside the shade launch, so only
                                         `items` (rays traced) is counted here; their time is part of SHADE */
 #define ORION_KERNEL_SHADE       2   /* surface evaluation, roulette, next-ray generation */
-#define ORION_KERNEL_GENERATE    3   /* primary-ray generation */
+#define ORION_KERNEL_GENERATE    3   /* primary-ray generation (part of the first closest-hit launch: no launches of its own) */
 #define ORION_KERNEL_RESOLVE     4   /* per-sample accumulation into the image */
 #define ORION_KERNEL_ANY_HIT     5   /* any-hit traversal */
-#define ORION_KERNEL_COUNT       6
+#define ORION_KERNEL_TAIL        6   /* the last bounces of a batch, one path per wave (items: paths handed over) */
+#define ORION_KERNEL_COUNT       7
 
 typedef struct OrionKernelStats {
     uint64_t launches;
@@ -167,7 +168,11 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
 
 /* Tuning knobs, mainly for A/B measurements.  Known names:
  *   "traversal"   0 = choose per scene (default), 1 = per-lane traversal,
- *                 2 = wave-synchronous traversal (scene data through scalar loads)
+ *                 2 = wave-synchronous traversal (scene data through scalar loads),
+ *                 3 = one ray per wave at a time (scenes of at most 64 inner nodes +
+ *                 triangles; slow on batches, it exists to test the walk the tail kernel uses)
+ *   "tail_paths"  a render batch hands its remaining paths to the one-path-per-wave
+ *                 tail kernel once at most this many are left (0 = never; small scenes only)
  *   "batch_paths" upper bound on paths in flight per render batch
  *   "hand_scheduled" 1 (default) = the wave-synchronous closest-hit walk runs its
  *                 hand-scheduled form, 0 = the compiler's form of the same loop

@@ -27,7 +27,7 @@ assert HIT_DTYPE.itemsize == 20
 
 TEX_RGB_F32, TEX_RGB_U8, TEX_RGBA_U8, TEX_GRAY_U8 = 0, 1, 2, 3
 
-KERNEL_NAMES = ["closest_hit", "shadow", "shade", "generate", "resolve", "any_hit"]
+KERNEL_NAMES = ["closest_hit", "shadow", "shade", "generate", "resolve", "any_hit", "tail"]
 
 
 class _Texture(C.Structure):

@@ -49,6 +49,21 @@ struct TriAttr {
 };
 static_assert(sizeof(TriAttr) == 64, "TriAttr layout");
 
+// One lane's share of the one-ray-per-wave walk (scenes of at most 64 inner nodes + triangles):
+// item i, in visit order, is either an inner node's box or a triangle, with the set of inner
+// nodes above it.  64 bytes.
+struct WaveItem {
+    float a[3];          // box: lo        triangle: v0
+    uint32_t gtri;       //                triangle: scene-wide id
+    float b[3];          // box: hi        triangle: e1
+    uint32_t kind;       // 0 unused, 1 box, 2 triangle
+    float c[3];          //                triangle: e2
+    uint32_t pad;
+    uint32_t anc_lo, anc_hi;   // bit i set: item i is an inner node whose subtree holds this item
+    uint32_t pad2[2];
+};
+static_assert(sizeof(WaveItem) == 64, "WaveItem layout");
+
 struct Texture {
     uint32_t offset;   // element offset into texels_f32 (floats) or texels_u8 (bytes)
     uint32_t width, height;
@@ -79,6 +94,8 @@ struct SceneView {
     uint32_t n_meshes;
     uint32_t n_emissive;
     uint32_t hand_scheduled;      // 1: wave-synchronous closest hit through traverse_wave_closest_asm
+    const WaveItem* items;        // one-ray-per-wave table, n_items entries (0: the scene is too large for it)
+    uint32_t n_items;
 };
 
 // Closest-hit record kept in the queues: 16 bytes.  gtri == kInvalid is a miss.

@@ -211,6 +211,96 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
 }
 
 // ---------------------------------------------------------------------------
+// One ray per wave: every lane holds the SAME ray and takes one item of the
+// scene (an inner node's box or a triangle), so the whole walk is one box test
+// or one triangle test deep.  For the few thousand rays of a path tracer's
+// last bounces, where a launch lasts as long as one ray's serial walk, this is
+// what shortens it (some 50 dependent steps -> 1).
+// The serial walk's result, restated for a parallel evaluation:
+//   * a triangle is visited iff every inner node above it has its box hit
+//     (leaves are not box-tested, orion/avx/sbvh.cpp:50-59);
+//   * a visited triangle that passes det/u/v and t >= 0 is accepted iff
+//     !(t > best so far) (orion/geometry.hpp:127), so the final hit is the
+//     smallest t and, among equal t, the LAST in visit order;
+//   * a NaN t passes both comparisons and then lets the next candidate replace
+//     it: the walk effectively restarts after the last NaN candidate.
+// Requires h.t == +inf on entry (true at every call site) and full exec.
+// ---------------------------------------------------------------------------
+template <bool ANY>
+__device__ __forceinline__ void traverse_one(const SceneView& S, V3 o, V3 d, HitRec& h) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const float4* ip = reinterpret_cast<const float4*>(S.items + lane);
+    const float4 A = ip[0], B = ip[1], C = ip[2], D = ip[3];
+    const uint32_t kind = __float_as_uint(B.w);
+    const uint64_t anc = (uint64_t)__float_as_uint(D.x) | ((uint64_t)__float_as_uint(D.y) << 32);
+    const V3 inv = ray_inverse(d);
+    // boxes
+    const bool in = slab_safe(o, inv) ? slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv) : slab_hit(A.x, A.y, A.z, B.x, B.y, B.z, o, inv);
+    const uint64_t box_hit = __ballot(kind == 1u && in);
+    // triangles: Triangle::intersect against t = +inf, every stage computed
+    const float eps = 0.000001f;
+    const V3 v0 = mk(A.x, A.y, A.z), e1 = mk(B.x, B.y, B.z), e2 = mk(C.x, C.y, C.z);
+    const V3 pvec = cross(d, e2);
+    const float det = dot_raw(e1, pvec);
+    bool ok = !(det > -eps && det < eps);
+    const float inv_det = 1.0f / det;
+    const V3 tvec = o - v0;
+    const float du = dot_raw(tvec, pvec);
+    const float u = du * inv_det;
+    ok = ok && !(u < 0 || u > 1);
+    const V3 qvec = cross(tvec, e1);
+    const float dv = dot_raw(d, qvec);
+    const float v = dv * inv_det;
+    ok = ok && !(v < 0 || u + v > 1);
+    const float dt = dot_raw(e2, qvec);
+    const float t = dt * inv_det;
+    ok = ok && !(t < 0);
+    bool cand = kind == 2u && ok && (anc & ~box_hit) == 0ull;
+    uint64_t cm = __ballot(cand);
+    if (cm == 0ull) return;
+    if (ANY) { h.gtri = 0u; return; }   // the callers of the any-hit form only ask whether there was one
+    const uint64_t nanm = __ballot(cand && t != t);
+    uint32_t winner;
+    bool decided = false;
+    if (nanm != 0ull) {
+        const uint32_t last_nan = 63u - (uint32_t)__builtin_clzll(nanm);
+        const uint64_t after = last_nan == 63u ? 0ull : (cm >> (last_nan + 1u)) << (last_nan + 1u);
+        if (after == 0ull) { winner = last_nan; decided = true; }
+        else { cm = after; cand = cand && lane > last_nan; }
+    }
+    if (!decided) {
+        float m = cand ? t : __builtin_inff();
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const float other = __shfl_xor(m, sft);
+            m = (other < m) ? other : m;
+        }
+        const uint64_t best = __ballot(cand && t == m);
+        winner = 63u - (uint32_t)__builtin_clzll(best);
+    }
+    winner = __builtin_amdgcn_readfirstlane(winner);
+    h.t = __shfl(canon(dt) * inv_det, (int)winner);
+    h.u = __shfl(canon(du) * inv_det, (int)winner);
+    h.v = __shfl(canon(dv) * inv_det, (int)winner);
+    h.gtri = __shfl(__float_as_uint(A.w), (int)winner);
+}
+
+// The same walk for a wave whose lanes hold different rays: one ray after the other.
+template <bool ANY>
+__device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
+    const uint64_t todo = __ballot(active);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t r = 0; r < 64u; r++) {
+        if (!((todo >> r) & 1ull)) continue;
+        const V3 ro = mk(__shfl(o.x, (int)r), __shfl(o.y, (int)r), __shfl(o.z, (int)r));
+        const V3 rd = mk(__shfl(d.x, (int)r), __shfl(d.y, (int)r), __shfl(d.z, (int)r));
+        HitRec hr; hr.t = __builtin_inff(); hr.u = 0.0f; hr.v = 0.0f; hr.gtri = kInvalid;
+        traverse_one<ANY>(S, ro, rd, hr);
+        if (lane == r) h = hr;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The closest-hit wave walk, hand-scheduled.  Same algorithm and the same FP32
 // operations in the same order as traverse_wave<false> with slab_hit_fast and
 // tri_hit (the division is the compiler's own correctly rounded sequence), but

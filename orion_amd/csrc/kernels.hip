@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/orion_hip.h"
@@ -33,12 +34,20 @@ namespace {
 
 constexpr int kBlock = 256;
 
-enum { MODE_LANE = 0, MODE_WAVE = 1 };
+// MODE_LANE: every lane walks on its own.  MODE_WAVE: the wave walks the node array once for its 64
+// rays.  MODE_EACH: the wave takes its rays one at a time, all lanes on one ray (a way to run the
+// one-ray-per-wave walk on ordinary batches; its use is testing).  MODE_SAME: the caller guarantees
+// that all lanes hold the same ray and the same `active` (the tail kernel).
+enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3 };
 
 template <int MODE, bool ANY>
 __device__ __forceinline__ void traverse(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
     if (MODE == MODE_WAVE) {
         traverse_wave<ANY>(S, o, d, h, active);
+    } else if (MODE == MODE_EACH) {
+        traverse_one_each<ANY>(S, o, d, h, active);
+    } else if (MODE == MODE_SAME) {
+        if (active) traverse_one<ANY>(S, o, d, h);
     } else {
         if (active) traverse_lane<ANY>(S, o, d, h);
     }
@@ -257,31 +266,16 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
 }
 
 // One bounce of RayTracer::trace after the closest hit is known
-// (orion/raytracer.cpp:116-206).  POINT selects the point-light branch.
-// Input: the `*n_live` vertex records k_extend left (every one of them a hit); the grid is sized
-// for the ray count, blocks past the live count leave at once.
+// (orion/raytracer.cpp:116-206).  POINT selects the point-light branch.  Adds the vertex's light
+// to rad[pid] (lanes with `writer` set do the store) and returns whether the path goes on, with
+// the next ray's origin (the biased hit point), direction and throughput.
 template <int MODE, bool POINT>
-__global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, uint32_t depth, Queues qin,
-                                                  const unsigned long long* __restrict__ n_live,
-                                                  const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
-                                                  float4* __restrict__ rad) {
-    const uint32_t n = (uint32_t)*n_live;
-    if (blockIdx.x * kBlock >= n) return;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = i < n;
-    V3 o = splat(0.0f), d = splat(1.0f), T = splat(0.0f);
-    uint32_t pid = 0, pixel = 0, sample = 0;
-    HitRec h = miss_rec();
-    if (live) {
-        const float4 a = qin.o[i], b = qin.d[i], c = qin.T[i];
-        o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); T = mk(c.x, c.y, c.z);
-        pid = __float_as_uint(a.w); pixel = __float_as_uint(b.w); sample = __float_as_uint(c.w);
-        const float4 hr = reinterpret_cast<const float4*>(hits)[i];
-        h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
-    }
-
+__device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams& F, uint32_t depth, bool live, bool writer,
+                                           V3 o, V3 d, V3 T, uint32_t pid, uint32_t pixel, uint32_t sample, const HitRec& h,
+                                           float4* __restrict__ rad, V3& biased, V3& next_d, V3& next_T) {
     const float bias = 1e-3f;
-    V3 normal = splat(0.0f), hitPos = splat(0.0f), biased = splat(0.0f), color = splat(0.0f);
+    V3 normal = splat(0.0f), hitPos = splat(0.0f), color = splat(0.0f);
+    biased = splat(0.0f);
     float tu = 0.0f, tv = 0.0f;
     uint32_t mesh_id = 0;
     if (live) {
@@ -298,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
     }
 
     bool cont = false;
-    V3 next_d = splat(0.0f), next_T = splat(0.0f);
+    next_d = splat(0.0f); next_T = splat(0.0f);
 
     if (!POINT) {
         // Direct light: light_samples points on every emissive mesh (orion/raytracer.cpp:133-159)
@@ -330,9 +324,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
             color = color + contrib * inv_ls;
         }
         if (live) {
-            const float4 r0 = rad[pid];
-            const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
-            rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            if (writer) {
+                const float4 r0 = rad[pid];
+                const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
+                rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            }
             if (depth < F.max_depth) {
                 // Russian roulette on max(kd), then a cosine-weighted direction (orion/raytracer.cpp:164-194)
                 const float cc = tpl_max(tpl_max(kd.x, kd.y), kd.z);
@@ -374,9 +370,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
                 color = color + color_phong(ka, kd, ks, shininess, d, normal, hitPos, lpos, ld3(F.lights[li].color), F.lights[li].intensity);
         }
         if (live) {
-            const float4 r0 = rad[pid];
-            const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
-            rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            if (writer) {
+                const float4 r0 = rad[pid];
+                const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
+                rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+            }
             if (depth < F.max_depth) {   // mirror bounce weighted by the specular texel (orion/raytracer.cpp:203-206)
                 next_d = reflect(d, normal);
                 next_T = T * ks;
@@ -385,11 +383,67 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
         }
     }
 
+    return cont;
+}
+
+// Input: the `*n_live` vertex records k_extend left (every one of them a hit); the grid is sized
+// for the ray count, blocks past the live count leave at once.
+template <int MODE, bool POINT>
+__global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, uint32_t depth, Queues qin,
+                                                  const unsigned long long* __restrict__ n_live,
+                                                  const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
+                                                  float4* __restrict__ rad) {
+    const uint32_t n = (uint32_t)*n_live;
+    if (blockIdx.x * kBlock >= n) return;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n;
+    V3 o = splat(0.0f), d = splat(1.0f), T = splat(0.0f);
+    uint32_t pid = 0, pixel = 0, sample = 0;
+    HitRec h = miss_rec();
+    if (live) {
+        const float4 a = qin.o[i], b = qin.d[i], c = qin.T[i];
+        o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); T = mk(c.x, c.y, c.z);
+        pid = __float_as_uint(a.w); pixel = __float_as_uint(b.w); sample = __float_as_uint(c.w);
+        const float4 hr = reinterpret_cast<const float4*>(hits)[i];
+        h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
+    }
+    V3 biased, next_d, next_T;
+    const bool cont = shade_core<MODE, POINT>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
     const uint32_t slot = queue_slot(cont, false, out_count);
     if (cont) {
         qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
         qout.d[slot] = make_float4(next_d.x, next_d.y, next_d.z, __uint_as_float(pixel));
         qout.T[slot] = make_float4(next_T.x, next_T.y, next_T.z, __uint_as_float(sample));
+    }
+}
+
+// The last bounces of a batch, one PATH per wave.  Once a few thousand rays are left, a bounce's
+// two launches last as long as one ray's serial walk plus one vertex's serial shading, dozens of
+// times in a row while the chip idles.  Here every wave takes one of the remaining rays and
+// follows its path to the end: all 64 lanes hold the same path, the closest hit is one parallel
+// step (traverse_one), the shading runs redundantly on all lanes with lane 0 storing, and no
+// queue, count or launch stands between two bounces.  Same operations per path as
+// k_extend + k_shade, hence the same radiance bit for bit.
+// `prev`: counter slot of the bounce that produced the rays (prev[1] = how many); depth0 = the
+// depth of those rays.  The rays traced here are not counted in the profiling statistics (a few
+// per mille of a frame's rays; counting them would cost an atomic per wave).
+template <bool POINT>
+__global__ __launch_bounds__(kBlock) void k_tail(SceneView S, FrameParams F, uint32_t depth0, Queues qin,
+                                                 const unsigned long long* __restrict__ prev, float4* __restrict__ rad) {
+    const uint32_t n = (uint32_t)prev[1];
+    const uint32_t path = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (path >= n) return;   // whole waves leave: every lane of a wave has the same path
+    const float4 a = qin.o[path], b = qin.d[path], c = qin.T[path];
+    V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z), T = mk(c.x, c.y, c.z);
+    const uint32_t pid = __float_as_uint(a.w), pixel = __float_as_uint(b.w), sample = __float_as_uint(c.w);
+    const bool writer = lane_id() == 0;
+    for (uint32_t depth = depth0; depth <= F.max_depth; depth++) {
+        HitRec h = miss_rec();
+        traverse_one<false>(S, o, d, h);
+        if (h.gtri == kInvalid) break;
+        V3 biased, next_d, next_T;
+        if (!shade_core<MODE_SAME, POINT>(S, F, depth, true, writer, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T)) break;
+        o = biased; d = next_d; T = next_T;
     }
 }
 
@@ -458,7 +512,8 @@ struct OrionScene {
     std::vector<uint32_t> mesh_tri_base;
     uint32_t n_nodes = 0, n_tris = 0;
     // options
-    int traversal = 0;                // 0 auto, 1 lane, 2 wave
+    int traversal = 0;                // 0 auto, 1 lane, 2 wave, 3 one ray per wave at a time
+    uint32_t tail_paths = 1u << 16;   // hand a batch's last paths to k_tail once this few are left
     uint64_t batch_paths = 64u << 20;     // paths in flight per batch (128 B of queues each)
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
@@ -477,6 +532,7 @@ struct OrionScene {
     int mode() const {
         if (traversal == 1) return MODE_LANE;
         if (traversal == 2) return MODE_WAVE;
+        if (traversal == 3) return MODE_EACH;
         // The wave-synchronous walk costs the union of the lanes' paths, so it only
         // pays while the whole tree is about as small as one ray's own path.
         return n_nodes <= 64 ? MODE_WAVE : MODE_LANE;
@@ -604,16 +660,28 @@ int await_counters(OrionScene* s, const unsigned long long* slot, uint32_t tag, 
     }
 }
 
+// Calls f(std::integral_constant<int, MODE>) for the scene's traversal mode.
+template <typename F>
+void with_mode(int mode, F&& f) {
+    switch (mode) {
+        case MODE_WAVE: f(std::integral_constant<int, MODE_WAVE>()); break;
+        case MODE_EACH: f(std::integral_constant<int, MODE_EACH>()); break;
+        default: f(std::integral_constant<int, MODE_LANE>()); break;
+    }
+}
+
 int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_out) {
-    launch(s, ORION_KERNEL_CLOSEST_HIT, n, s->mode() == MODE_WAVE ? k_closest_api<MODE_WAVE> : k_closest_api<MODE_LANE>,
-           dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
+    with_mode(s->mode(), [&](auto M) {
+        launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_closest_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
+    });
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_anyhit(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, uint8_t* d_out) {
-    launch(s, ORION_KERNEL_ANY_HIT, n, s->mode() == MODE_WAVE ? k_anyhit_api<MODE_WAVE> : k_anyhit_api<MODE_LANE>,
-           dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
+    with_mode(s->mode(), [&](auto M) {
+        launch(s, ORION_KERNEL_ANY_HIT, n, k_anyhit_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
+    });
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -746,6 +814,39 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         tri_base += ntri;
     }
 
+    // One-ray-per-wave table: inner nodes and triangles in visit order, one per lane, each with the
+    // set of inner nodes above it (the nodes whose subtree [index, skip) contains it).
+    std::vector<WaveItem> items;
+    {
+        size_t n_inner = 0;
+        for (const Node& nd : nodes) if (!(nd.b & kLeafFlag)) n_inner++;
+        if (!nodes.empty() && n_inner + tris.size() <= 64) {
+            std::vector<uint32_t> item_of_node(nodes.size(), kInvalid);
+            for (uint32_t ni = 0; ni < nodes.size(); ni++) {
+                const Node& nd = nodes[ni];
+                uint64_t anc = 0;
+                for (uint32_t a = 0; a < ni; a++)
+                    if (!(nodes[a].b & kLeafFlag) && nodes[a].a > ni) anc |= 1ull << item_of_node[a];
+                WaveItem it{};
+                it.anc_lo = (uint32_t)anc; it.anc_hi = (uint32_t)(anc >> 32);
+                if (!(nd.b & kLeafFlag)) {
+                    item_of_node[ni] = (uint32_t)items.size();
+                    std::memcpy(it.a, nd.lo, 12); std::memcpy(it.b, nd.hi, 12);
+                    it.kind = 1;
+                    items.push_back(it);
+                } else {
+                    for (uint32_t k = 0; k < (nd.b & ~kLeafFlag); k++) {
+                        const Tri& t = tris[nd.a + k];
+                        std::memcpy(it.a, t.v0, 12); std::memcpy(it.b, t.e1, 12); std::memcpy(it.c, t.e2, 12);
+                        it.gtri = t.gtri; it.kind = 2;
+                        items.push_back(it);
+                    }
+                }
+            }
+            items.resize(64, WaveItem{});   // every lane reads an entry
+        }
+    }
+
     std::vector<Texture> dtex(n_textures);
     std::vector<float> texf;
     std::vector<uint8_t> texb;
@@ -789,6 +890,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     v.n_nodes = (uint32_t)nodes.size(); v.n_tris = (uint32_t)tris.size();
     v.n_meshes = n_meshes; v.n_emissive = (uint32_t)emissive.size();
     v.hand_scheduled = 1;
+    if (!items.empty()) { if ((rc = upload(s, items, &v.items))) return bail(rc); v.n_items = 64; }
     s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
     for (const Mesh& dm : dmeshes) s->mesh_tri_base.push_back(dm.tri_base);
     *out = s;
@@ -814,13 +916,19 @@ int orion_hip_scene_destroy(OrionScene* s) {
 int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
     if (!s || !name) return fail(1, "set_option: null argument");
     if (!std::strcmp(name, "traversal")) {
-        if (value < 0 || value > 2) return fail(1, "set_option: traversal must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(1, "set_option: traversal must be 0, 1, 2 or 3");
+        if (value == 3 && s->view.n_items == 0) return fail(1, "set_option: the scene is too large for one ray per wave (more than 64 inner nodes + triangles)");
         s->traversal = (int)value;
         return 0;
     }
     if (!std::strcmp(name, "hand_scheduled")) {
         if (value < 0 || value > 1) return fail(1, "set_option: hand_scheduled must be 0 or 1");
         s->view.hand_scheduled = (uint32_t)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "tail_paths")) {
+        if (value < 0 || value > (int64_t)1 << 24) return fail(1, "set_option: tail_paths out of range");
+        s->tail_paths = (uint32_t)value;
         return 0;
     }
     if (!std::strcmp(name, "batch_paths")) {
@@ -921,6 +1029,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     HitRec* d_hits = static_cast<HitRec*>(s->hits.p);
     float4* d_rad = static_cast<float4*>(s->rad.p);
     const int mode = s->mode();
+    const bool tail_ok = s->view.n_items != 0 && mode != MODE_LANE && s->tail_paths != 0;
     const uint64_t rays_per_vertex = point ? p->n_lights : (uint64_t)p->light_samples * s->view.n_emissive;
 
     for (uint64_t sb = p->spp_begin; sb < p->spp_end; sb += per_batch) {
@@ -933,7 +1042,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         // [1] rays k_shade emitted for bounce d + 1.  The kernels read their counts on the device;
         // the host only needs an upper bound to size the grids and the zero that ends the loop, and
         // takes both from the bounce kLag launches back.
-        const uint32_t n_bins = (mode == MODE_WAVE) ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
+        const uint32_t n_bins = (mode != MODE_LANE) ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
         uint32_t bound = n0;          // >= the number of rays entering the next bounce to launch
         uint32_t consumed = 0;        // bounces whose counters the host has read
         uint32_t launched = 0;
@@ -965,23 +1074,30 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                 launch(s, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((bound + tile - 1) / tile), dim3(kBlock), s->view, F, d_rad, qa,
                        prev, bound, qb, d_hits, cnt, clear, s->h_count + 2 * prev_slot, tags[prev_slot], n_bins);
             };
-            if (depth == 0) {   // primary rays are generated inside the launch
-                if (mode == MODE_WAVE) { if (wide) extend(k_extend<MODE_WAVE, kRaysWide, true>); else extend(k_extend<MODE_WAVE, 1, true>); }
-                else { if (wide) extend(k_extend<MODE_LANE, kRaysWide, true>); else extend(k_extend<MODE_LANE, 1, true>); }
-            } else {
-                if (mode == MODE_WAVE) { if (wide) extend(k_extend<MODE_WAVE, kRaysWide, false>); else extend(k_extend<MODE_WAVE, 1, false>); }
-                else { if (wide) extend(k_extend<MODE_LANE, kRaysWide, false>); else extend(k_extend<MODE_LANE, 1, false>); }
-            }
-            launch(s, ORION_KERNEL_SHADE, 0,
-                   mode == MODE_WAVE ? (point ? k_shade<MODE_WAVE, true> : k_shade<MODE_WAVE, false>)
-                                     : (point ? k_shade<MODE_LANE, true> : k_shade<MODE_LANE, false>),
-                   dim3(grid_for(bound)), dim3(kBlock), s->view, F, depth, qb, cnt, d_hits, qa, cnt + 1, d_rad);
+            with_mode(mode, [&](auto M) {
+                constexpr int MODE = decltype(M)::value;
+                if (depth == 0) {   // primary rays are generated inside the launch
+                    if (wide) extend(k_extend<MODE, kRaysWide, true>); else extend(k_extend<MODE, 1, true>);
+                } else {
+                    if (wide) extend(k_extend<MODE, kRaysWide, false>); else extend(k_extend<MODE, 1, false>);
+                }
+                launch(s, ORION_KERNEL_SHADE, 0, point ? k_shade<MODE, true> : k_shade<MODE, false>,
+                       dim3(grid_for(bound)), dim3(kBlock), s->view, F, depth, qb, cnt, d_hits, qa, cnt + 1, d_rad);
+            });
             HIP_TRY(hipGetLastError());
             launched = depth + 1;
             if (depth >= kLag) {
                 if (int rc = consume()) return rc;
                 if (rays_in == 0) break;          // bounce `consumed` has no rays; the ones launched past it find none either
                 bound = (uint32_t)rays_in;
+                // Few paths left: one launch takes each of them to its end (one wave per path).  The
+                // rays it starts from are the ones the last shade launch emitted, at most `bound`.
+                if (tail_ok && bound <= s->tail_paths && launched <= p->max_depth) {
+                    launch(s, ORION_KERNEL_TAIL, bound, point ? k_tail<true> : k_tail<false>, dim3((bound + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
+                           s->view, F, launched, qa, d_count + 2 * ((launched - 1) % kRing), d_rad);
+                    HIP_TRY(hipGetLastError());
+                    break;
+                }
             }
         }
         if (s->profiling) {   // the statistics want every bounce; the last one has no extend launch after it

@@ -337,3 +337,54 @@ def test_hand_scheduled_walk_equals_the_compilers(gpu):
         assert np.array_equal(bits(a[0][f]), bits(b[0][f])), f
     assert (a[0]["mesh"] != gpu.INVALID).sum() > n // 2
     assert np.array_equal(bits(a[1]), bits(b[1]))
+
+
+@pytest.mark.parametrize("name", ["cornell", "view_test"])
+def test_one_ray_per_wave_golden(gpu, name):
+    """The walk the tail kernel uses (all 64 lanes on one ray: one box or triangle each, the serial
+    walk's acceptance order restated as a reduction) against the same golden vectors, edge cases and
+    NaN rays included, and against the oracle on a large batch."""
+    g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
+    sc = scene_for(gpu, name)
+    sc.set_option("traversal", 3)
+    for b in BATCHES:
+        ids, tuv = hits_to_arrays(sc.closest_hit(g[f"{b}_org"], g[f"{b}_dir"]))
+        assert np.array_equal(ids, g[f"{b}_ids"]), f"{name}/{b}: ids"
+        assert np.array_equal(bits(tuv), bits(g[f"{b}_tuv"])), f"{name}/{b}: t,u,v bits"
+        occ = sc.any_hit(g[f"{b}_org"], g[f"{b}_dir"])
+        assert np.array_equal(occ.astype(bool), g[f"{b}_ids"][:, 0] != gpu.INVALID), f"{name}/{b}: any hit"
+    model = conftest.load_model(name)
+    o, d = raygen.box_rays(model, 1 << 18, seed=22)
+    ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+    oid, otuv = oracle_for(name).closest_hit(o, d, threads=8)
+    assert np.array_equal(ids, oid) and np.array_equal(bits(tuv), bits(otuv))
+    sc.set_option("traversal", 0)
+
+
+def test_one_ray_per_wave_needs_a_small_scene(gpu):
+    sc = scene_for(gpu, "nanosuit")
+    with pytest.raises(RuntimeError, match="too large"):
+        sc.set_option("traversal", 3)
+
+
+@pytest.mark.parametrize("point", [False, True])
+def test_tail_kernel_changes_nothing(gpu, point):
+    """Handing the last paths of a batch to the one-path-per-wave kernel is a scheduling decision:
+    whatever the threshold, the image keeps its bits."""
+    sc = gpu.Scene(conftest.load_model("cornell"), device=0)
+    eye, look, up, yv = CORNELL_CAM
+    W, H = 160, 96
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    lights = np.float32([[0.0, 1.6, 0.5, 1.0, 0.9, 0.8, 4.0]]) if point else None
+    imgs = []
+    for tail in (0, 1 << 9, 1 << 13, 1 << 24):   # never, late, early, from the third bounce on
+        sc.set_option("tail_paths", tail)
+        sc.profile(True)
+        imgs.append(sc.render(cam, W, H, 0, 8, 2, 30, seed=9, lights=lights).copy())
+        st = sc.profile_read()
+        sc.profile(False)
+        assert (st["tail"]["launches"] > 0) == (tail > 0), (tail, st["tail"])
+    sc.close()
+    assert np.isfinite(imgs[0]).all() and imgs[0][:, :, :3].max() > 0
+    for im in imgs[1:]:
+        assert np.array_equal(bits(im), bits(imgs[0]))
