@@ -12,7 +12,7 @@ import sys
 
 
 def kname(n):
-    for k in ("k_shade", "k_extend", "k_generate", "k_resolve", "k_query_api"):
+    for k in ("k_shade", "k_extend", "k_tail", "k_resolve", "k_closest_api", "k_anyhit_api"):
         if k in n:
             return k
     return None
