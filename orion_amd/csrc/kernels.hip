@@ -1,19 +1,8 @@
-// HIP kernels for gfx950 (MI355X) and the C ABI declared in include/orion_hip.h.
-//
-// Pipeline of one render batch (a wavefront path tracer over ray queues in HBM):
-//   generate      one primary ray per (pixel, sample)                 orion/raytracer.cpp:72-80
-//   per bounce:
-//     extend      closest hit of every queued ray                     orion/model.hpp:52-62, orion/avx/sbvh.cpp:36-83
-//     shade       surface + direct light (light-sample rays traced
-//                 in place) + roulette + next ray, survivors
-//                 compacted into the next queue with a wave ballot    orion/raytracer.cpp:116-206
-//   resolve       per-pixel sum of the batch's samples, in sample
-//                 order, into the caller's accumulator                orion/raytracer.cpp:84-86
-// Every kernel is built twice: with the per-lane traversal and with the
-// wave-synchronous (scalar-load) traversal of intersect.h.
+// The C ABI declared in include/orion_hip.h: scene upload (flattening the host-built trees into the
+// device layout), the two ray-query entry points and the render loop that drives the kernels of
+// pathtrace.h.  Built for gfx950 (MI355X) only.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-
 
 #include <cmath>
 #include <cstdio>
@@ -23,445 +12,7 @@
 #include <vector>
 
 #include "../../include/orion_hip.h"
-#include "shading.h"
-
-using namespace orion_dev;
-
-// ===========================================================================
-// Kernels
-// ===========================================================================
-namespace {
-
-constexpr int kBlock = 256;
-
-// MODE_LANE: every lane walks on its own.  MODE_WAVE: the wave walks the node array once for its 64
-// rays.  MODE_EACH: the wave takes its rays one at a time, all lanes on one ray (a way to run the
-// one-ray-per-wave walk on ordinary batches; its use is testing).  MODE_SAME: the caller guarantees
-// that all lanes hold the same ray and the same `active` (the tail kernel).
-enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3 };
-
-template <int MODE, bool ANY>
-__device__ __forceinline__ void traverse(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
-    if (MODE == MODE_WAVE) {
-        traverse_wave<ANY>(S, o, d, h, active);
-    } else if (MODE == MODE_EACH) {
-        traverse_one_each<ANY>(S, o, d, h, active);
-    } else if (MODE == MODE_SAME) {
-        if (active) traverse_one<ANY>(S, o, d, h);
-    } else {
-        if (active) traverse_lane<ANY>(S, o, d, h);
-    }
-}
-
-__device__ __forceinline__ HitRec miss_rec() { HitRec h; h.t = INFINITY; h.u = 0.0f; h.v = 0.0f; h.gtri = kInvalid; return h; }
-
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// Block-level queue append.  Every thread of the block must call it.  Survivors are
-// counted per wave with a ballot, the four wave counts are combined through LDS and
-// ONE 64-bit atomic per block reserves the slots (low word: queue length, high word:
-// a statistics counter, here the number of shaded vertices).  One atomic per wave on a
-// single address would serialise at the memory side (~12 ns each) and bound the kernel.
-__device__ __forceinline__ uint32_t queue_slot(bool push, bool stat, unsigned long long* counter) {
-    __shared__ uint32_t s_cnt[kBlock / 64];
-    __shared__ uint32_t s_stat[kBlock / 64];
-    __shared__ uint32_t s_base;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint64_t m = __ballot(push);
-    const uint64_t ms = __ballot(stat);
-    if (lane_id() == 0) { s_cnt[wave] = (uint32_t)__popcll(m); s_stat[wave] = (uint32_t)__popcll(ms); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0, stat_total = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) { total += s_cnt[w]; stat_total += s_stat[w]; }
-        unsigned long long old = 0;
-        if (total | stat_total) old = atomicAdd(counter, (unsigned long long)total | ((unsigned long long)stat_total << 32));
-        s_base = (uint32_t)old;
-    }
-    __syncthreads();
-    uint32_t base = s_base;
-    for (uint32_t w = 0; w < wave; w++) base += s_cnt[w];
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    return base + rank;
-}
-
-// --- ray-query entry points --------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_closest_api(SceneView S, const float* __restrict__ org, const float* __restrict__ dir,
-                                                        uint32_t n, OrionHit* __restrict__ out) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = i < n;
-    V3 o = splat(0.0f), d = splat(1.0f);
-    if (active) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); }
-    HitRec h = miss_rec();
-    traverse<MODE, false>(S, o, d, h, active);
-    if (active) {
-        OrionHit r;
-        r.mesh = kInvalid; r.tri = kInvalid; r.t = h.t; r.u = h.u; r.v = h.v;
-        if (h.gtri != kInvalid) {
-            r.mesh = S.attrs[h.gtri].mesh;
-            r.tri = h.gtri - S.meshes[r.mesh].tri_base;
-        }
-        out[i] = r;
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_anyhit_api(SceneView S, const float* __restrict__ org, const float* __restrict__ dir,
-                                                       uint32_t n, uint8_t* __restrict__ out) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = i < n;
-    V3 o = splat(0.0f), d = splat(1.0f);
-    if (active) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); }
-    HitRec h = miss_rec();
-    traverse<MODE, true>(S, o, d, h, active);
-    if (active) out[i] = h.gtri != kInvalid ? 1 : 0;
-}
-
-// --- path tracing --------------------------------------------------------------
-struct Queues {
-    float4* o;    // origin.xyz, path id (index of the path's radiance slot)
-    float4* d;    // direction.xyz, pixel index (RNG counter word 0)
-    float4* T;    // throughput.xyz, absolute sample index (RNG counter word 1)
-};
-
-__device__ __forceinline__ void path_pixel(const FrameParams& F, uint32_t pid, uint32_t& pixel, uint32_t& sample, uint32_t& px, uint32_t& py) {
-    const uint32_t P = F.tile_w * F.tile_h;
-    const uint32_t k = pid / P, p = pid - k * P;
-    py = F.tile_y0 + p / F.tile_w;
-    px = F.tile_x0 + p % F.tile_w;
-    pixel = py * F.width + px;
-    sample = F.spp_begin + k;
-}
-
-// Primary ray of path `pid` as its three queue records (orion/raytracer.cpp:53-72).
-__device__ __forceinline__ void primary_ray(const FrameParams& F, uint32_t pid, float4& qo, float4& qd, float4& qT) {
-    uint32_t pixel, sample, px, py;
-    path_pixel(F, pid, pixel, sample, px, py);
-    // per-sample jitter shared by all pixels (orion/raytracer.cpp:53-63)
-    const Words4 r = philox4x32_10(kPatternPixel, sample, 0u, kBlockPattern, F.seed_lo, F.seed_hi);
-    const float pixelX = 2.0f / (float)F.width, pixelY = 2.0f / (float)F.height;
-    const float jx = pixelX * u01(r.w[0]), jy = pixelY * u01(r.w[1]);
-    const float x = 2 * ((float)px / (float)F.width) - 1;
-    const float y = 2 * ((float)py / (float)F.height) - 1;
-    const float xs = x + jx, ys = -(y + jy);
-    const V3 dir = (ld3(F.front) + ld3(F.right) * xs) + ld3(F.up) * ys;
-    qo = make_float4(F.eye[0], F.eye[1], F.eye[2], __uint_as_float(pid));
-    qd = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pixel));
-    qT = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
-}
-
-// Rays per thread of k_extend: kRaysWide while the queue is long (larger tiles group better and
-// amortise the block's bookkeeping), 1 once a bounce no longer fills the machine, where the
-// launch time is one thread's serial work and more blocks are the only way to shorten it.
-constexpr uint32_t kRaysWide = 4;
-constexpr uint32_t kTileWide = kBlock * kRaysWide;
-constexpr uint32_t kNarrowBelow = 1u << 21;   // rays; about one ray per thread slot of the chip x 4
-constexpr uint32_t kMaxBins = 64;
-
-// Closest hit of every queued ray (orion/model.hpp:52-62).  Rays that miss end here: a miss
-// contributes nothing (orion/raytracer.cpp:113-114).  Rays that hit leave as complete path-vertex
-// records (origin, direction, throughput, ids + hit), compacted into `qout`/`hits`, and inside
-// each block's tile of kTile rays they are grouped by the triangle they hit (a counting sort
-// through LDS).  The shade kernel that consumes them therefore runs on waves whose vertices lie
-// on the same surface: its light-sample rays start on one plane and aim at one light, so the
-// wave-synchronous traversal's early exits hold for whole waves, and its material fetches are
-// uniform.  n_bins = number of triangle bins (<= kMaxBins; larger ids share the last bin), 1 = no grouping.
-// The ray count is read on the device (prev[1], written by the previous bounce's shade launch;
-// prev == null: n_bound itself): the host sizes the grid from an older, larger count (n_bound)
-// and never has to wait for the exact one.  `clear` is a counter slot of a later bounce, zeroed
-// here.  The previous bounce's counters are final by now; one lane stores them to the host's
-// pinned mirror (`publish`), where the host polls for them.  Each count travels with the tag in
-// one 64-bit store, so the host needs no ordering between the two (and the kernel no fence,
-// which at system scope would write back and invalidate the L2).
-__device__ __forceinline__ void publish_counters(const unsigned long long* cnt, unsigned long long* publish, uint32_t tag) {
-    const unsigned long long hi = (unsigned long long)tag << 32;
-    __hip_atomic_store(publish, hi | (uint32_t)cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(publish + 1, hi | (uint32_t)cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ void k_publish(const unsigned long long* cnt, unsigned long long* publish, uint32_t tag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) publish_counters(cnt, publish, tag);
-}
-
-// GEN: the first bounce.  The rays are the primary rays, computed here from the path index
-// instead of being read from a queue (no generate pass, no 64 B/path round trip through HBM), and
-// every path's radiance slot is zeroed.
-template <int MODE, uint32_t kRaysPerThread, bool GEN>
-__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, float4* __restrict__ rad,
-                                                   Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
-                                                   Queues qout, HitRec* __restrict__ hits, unsigned long long* __restrict__ counter,
-                                                   unsigned long long* __restrict__ clear, unsigned long long* publish, uint32_t tag, uint32_t n_bins) {
-    constexpr uint32_t kTile = kBlock * kRaysPerThread;   // rays per block
-    __shared__ float4 s_hit[kTile];
-    __shared__ uint16_t s_rank[kTile];
-    __shared__ uint32_t s_cnt[kMaxBins];
-    __shared__ uint32_t s_off[kMaxBins];
-    __shared__ uint32_t s_base;
-    const uint32_t tile0 = blockIdx.x * kTile;
-    uint32_t n = n_bound;
-    if (prev) { const unsigned long long m = prev[1]; if (m < n) n = (uint32_t)m; }
-    // Block 0's housekeeping stores come after the traversal on purpose: a store ahead of the
-    // scene loads would keep the compiler from issuing them as scalar loads.
-    auto housekeeping = [&]() {
-        if (blockIdx.x != 0) return;
-        if (threadIdx.x < 2) clear[threadIdx.x] = 0ull;
-        if (prev && threadIdx.x == 0) publish_counters(prev, publish, tag);
-    };
-    if (tile0 >= n) { housekeeping(); return; }
-    if (threadIdx.x < kMaxBins) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t k = 0; k < kRaysPerThread; k++) {
-        const uint32_t slot = k * kBlock + threadIdx.x;
-        const uint32_t i = tile0 + slot;
-        const bool active = i < n;
-        V3 o = splat(0.0f), d = splat(1.0f);
-        if (active) {
-            float4 a, b, c;
-            if (GEN) primary_ray(F, i, a, b, c);
-            else { a = qin.o[i]; b = qin.d[i]; }
-            o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
-        }
-        HitRec h = miss_rec();
-        traverse<MODE, false>(S, o, d, h, active);
-        s_hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.gtri));
-        if (h.gtri != kInvalid) {
-            const uint32_t bin = min(h.gtri, n_bins - 1u);
-            s_rank[slot] = (uint16_t)atomicAdd(&s_cnt[bin], 1u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {   // exclusive scan of the bin counts by the first wave (kMaxBins == 64 lanes)
-        const uint32_t c = s_cnt[threadIdx.x];
-        uint32_t incl = c;
-#pragma unroll
-        for (int sft = 1; sft < 64; sft <<= 1) {
-            const uint32_t up = __shfl_up(incl, sft);
-            if ((int)threadIdx.x >= sft) incl += up;
-        }
-        s_off[threadIdx.x] = incl - c;
-        if (threadIdx.x == 63) s_base = incl ? (uint32_t)atomicAdd(counter, (unsigned long long)incl) : 0u;
-    }
-    __syncthreads();
-    const uint32_t base = s_base;
-    for (uint32_t k = 0; k < kRaysPerThread; k++) {
-        const uint32_t slot = k * kBlock + threadIdx.x;
-        const float4 h = s_hit[slot];
-        const uint32_t gtri = __float_as_uint(h.w);
-        if (gtri != kInvalid) {
-            const uint32_t i = tile0 + slot;
-            const uint32_t dst = base + s_off[min(gtri, n_bins - 1u)] + s_rank[slot];
-            float4 a, b, c;
-            if (GEN) primary_ray(F, i, a, b, c);
-            else { a = qin.o[i]; b = qin.d[i]; c = qin.T[i]; }
-            qout.o[dst] = a;
-            qout.d[dst] = b;
-            qout.T[dst] = c;
-            reinterpret_cast<float4*>(hits)[dst] = h;
-        }
-        if (GEN && tile0 + slot < n) rad[tile0 + slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    housekeeping();
-}
-
-// One bounce of RayTracer::trace after the closest hit is known
-// (orion/raytracer.cpp:116-206).  POINT selects the point-light branch.  Adds the vertex's light
-// to rad[pid] (lanes with `writer` set do the store) and returns whether the path goes on, with
-// the next ray's origin (the biased hit point), direction and throughput.
-template <int MODE, bool POINT>
-__device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams& F, uint32_t depth, bool live, bool writer,
-                                           V3 o, V3 d, V3 T, uint32_t pid, uint32_t pixel, uint32_t sample, const HitRec& h,
-                                           float4* __restrict__ rad, V3& biased, V3& next_d, V3& next_T) {
-    const float bias = 1e-3f;
-    V3 normal = splat(0.0f), hitPos = splat(0.0f), color = splat(0.0f);
-    biased = splat(0.0f);
-    float tu = 0.0f, tv = 0.0f;
-    uint32_t mesh_id = 0;
-    if (live) {
-        const Surface sf = surface_at(S, h.gtri, h.u, h.v);
-        mesh_id = sf.mesh; tu = sf.tu; tv = sf.tv;
-        normal = normalize(sf.normal);
-        hitPos = o + d * h.t;
-        biased = hitPos + normal * bias;
-        if (depth == 0) {   // primary ray sees an emissive surface (orion/raytracer.cpp:127-128)
-            const Mesh m = S.meshes[mesh_id];
-            const float dn = dot(normalize(d), -normal);
-            color = (tex_fetch(S, m.tex[kTexEmissive], tu, tv) * m.area) * dn;
-        }
-    }
-
-    bool cont = false;
-    next_d = splat(0.0f); next_T = splat(0.0f);
-
-    if (!POINT) {
-        // Direct light: light_samples points on every emissive mesh (orion/raytracer.cpp:133-159)
-        V3 kd = splat(0.0f);
-        if (live) kd = tex_fetch(S, S.meshes[mesh_id].tex[kTexDiffuse], tu, tv);
-        const float inv_ls = F.inv_light_samples;
-        for (uint32_t e = 0; e < S.n_emissive; e++) {
-            const uint32_t lmesh = S.emissive[e];
-            const Mesh lm = S.meshes[lmesh];
-            V3 contrib = splat(0.0f);
-            for (uint32_t l = 0; l < F.light_samples; l++) {
-                V3 target = splat(0.0f), sd = splat(1.0f);
-                float lint = 0.0f;
-                if (live) {
-                    const Words4 r = philox4x32_10(pixel, sample, depth, e * F.light_samples + l, F.seed_lo, F.seed_hi);
-                    light_point(S, lm, r, target, lint);
-                    sd = target - hitPos;
-                }
-                HitRec h2 = miss_rec();
-                traverse<MODE, false>(S, biased, sd, h2, live);
-                if (live && h2.gtri != kInvalid) {
-                    const Surface s2 = surface_at(S, h2.gtri, h2.u, h2.v);
-                    if (s2.mesh == lmesh) {   // the sample is visible iff the closest hit is the light itself
-                        const V3 lcol = tex_fetch(S, lm.tex[kTexEmissive], s2.tu, s2.tv);
-                        contrib = contrib + color_brdf(kd, normal, hitPos, target, lcol, lint, normalize(s2.normal));
-                    }
-                }
-            }
-            color = color + contrib * inv_ls;
-        }
-        if (live) {
-            if (writer) {
-                const float4 r0 = rad[pid];
-                const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
-                rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-            }
-            if (depth < F.max_depth) {
-                // Russian roulette on max(kd), then a cosine-weighted direction (orion/raytracer.cpp:164-194)
-                const float cc = tpl_max(tpl_max(kd.x, kd.y), kd.z);
-                const Words4 r = philox4x32_10(pixel, sample, depth, kBlockBounce, F.seed_lo, F.seed_hi);
-                if (!(u01(r.w[0]) > cc)) {
-                    const float sin_theta = sqrtf(u01(r.w[1]));
-                    const float cos_theta = sqrtf(1 - sin_theta * sin_theta);
-                    const float psi = u01(r.w[2]) * 2.0f * 3.1415926535f;
-                    V3 tangent = cross(normal, mk(0.0f, 1.0f, 0.0f));
-                    if (dot(tangent, tangent) == 0.0f) tangent = cross(normal, mk(0.0f, 0.0f, 1.0f));
-                    const V3 bitangent = cross(normal, tangent);
-                    float sin_psi, cos_psi;
-                    sincosf(psi, &sin_psi, &cos_psi);
-                    const float a = sin_theta * cos_psi, b = sin_theta * sin_psi, c = cos_theta;
-                    next_d = (tangent * a + bitangent * b) + normal * c;
-                    next_T = (T * kd) / cc;
-                    cont = true;
-                }
-            }
-        }
-    } else {
-        // Point lights: any hit on the unbounded shadow ray occludes (orion/raytracer.cpp:196-201)
-        V3 ka = splat(0.0f), kd = splat(0.0f), ks = splat(0.0f);
-        float shininess = 0.0f;
-        if (live) {
-            const Mesh m = S.meshes[mesh_id];
-            ka = tex_fetch(S, m.tex[kTexAmbient], tu, tv);
-            kd = tex_fetch(S, m.tex[kTexDiffuse], tu, tv);
-            ks = tex_fetch(S, m.tex[kTexSpecular], tu, tv);
-            shininess = m.shininess;
-        }
-        for (uint32_t li = 0; li < F.n_lights; li++) {
-            const V3 lpos = ld3(F.lights[li].position);
-            V3 sd = splat(1.0f);
-            if (live) sd = lpos - hitPos;
-            HitRec h2 = miss_rec();
-            traverse<MODE, true>(S, biased, sd, h2, live);
-            if (live && h2.gtri == kInvalid)
-                color = color + color_phong(ka, kd, ks, shininess, d, normal, hitPos, lpos, ld3(F.lights[li].color), F.lights[li].intensity);
-        }
-        if (live) {
-            if (writer) {
-                const float4 r0 = rad[pid];
-                const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
-                rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-            }
-            if (depth < F.max_depth) {   // mirror bounce weighted by the specular texel (orion/raytracer.cpp:203-206)
-                next_d = reflect(d, normal);
-                next_T = T * ks;
-                cont = true;
-            }
-        }
-    }
-
-    return cont;
-}
-
-// Input: the `*n_live` vertex records k_extend left (every one of them a hit); the grid is sized
-// for the ray count, blocks past the live count leave at once.
-template <int MODE, bool POINT>
-__global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, uint32_t depth, Queues qin,
-                                                  const unsigned long long* __restrict__ n_live,
-                                                  const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
-                                                  float4* __restrict__ rad) {
-    const uint32_t n = (uint32_t)*n_live;
-    if (blockIdx.x * kBlock >= n) return;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = i < n;
-    V3 o = splat(0.0f), d = splat(1.0f), T = splat(0.0f);
-    uint32_t pid = 0, pixel = 0, sample = 0;
-    HitRec h = miss_rec();
-    if (live) {
-        const float4 a = qin.o[i], b = qin.d[i], c = qin.T[i];
-        o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); T = mk(c.x, c.y, c.z);
-        pid = __float_as_uint(a.w); pixel = __float_as_uint(b.w); sample = __float_as_uint(c.w);
-        const float4 hr = reinterpret_cast<const float4*>(hits)[i];
-        h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
-    }
-    V3 biased, next_d, next_T;
-    const bool cont = shade_core<MODE, POINT>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
-    const uint32_t slot = queue_slot(cont, false, out_count);
-    if (cont) {
-        qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
-        qout.d[slot] = make_float4(next_d.x, next_d.y, next_d.z, __uint_as_float(pixel));
-        qout.T[slot] = make_float4(next_T.x, next_T.y, next_T.z, __uint_as_float(sample));
-    }
-}
-
-// The last bounces of a batch, one PATH per wave.  Once a few thousand rays are left, a bounce's
-// two launches last as long as one ray's serial walk plus one vertex's serial shading, dozens of
-// times in a row while the chip idles.  Here every wave takes one of the remaining rays and
-// follows its path to the end: all 64 lanes hold the same path, the closest hit is one parallel
-// step (traverse_one), the shading runs redundantly on all lanes with lane 0 storing, and no
-// queue, count or launch stands between two bounces.  Same operations per path as
-// k_extend + k_shade, hence the same radiance bit for bit.
-// `prev`: counter slot of the bounce that produced the rays (prev[1] = how many); depth0 = the
-// depth of those rays.  The rays traced here are not counted in the profiling statistics (a few
-// per mille of a frame's rays; counting them would cost an atomic per wave).
-template <bool POINT>
-__global__ __launch_bounds__(kBlock) void k_tail(SceneView S, FrameParams F, uint32_t depth0, Queues qin,
-                                                 const unsigned long long* __restrict__ prev, float4* __restrict__ rad) {
-    const uint32_t n = (uint32_t)prev[1];
-    const uint32_t path = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (path >= n) return;   // whole waves leave: every lane of a wave has the same path
-    const float4 a = qin.o[path], b = qin.d[path], c = qin.T[path];
-    V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z), T = mk(c.x, c.y, c.z);
-    const uint32_t pid = __float_as_uint(a.w), pixel = __float_as_uint(b.w), sample = __float_as_uint(c.w);
-    const bool writer = lane_id() == 0;
-    for (uint32_t depth = depth0; depth <= F.max_depth; depth++) {
-        HitRec h = miss_rec();
-        traverse_one<false>(S, o, d, h);
-        if (h.gtri == kInvalid) break;
-        V3 biased, next_d, next_T;
-        if (!shade_core<MODE_SAME, POINT>(S, F, depth, true, writer, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T)) break;
-        o = biased; d = next_d; T = next_T;
-    }
-}
-
-// image[i][j] += tracedColor for the batch's samples in ascending order (orion/raytracer.cpp:84)
-__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams F, const float4* __restrict__ rad, float4* __restrict__ accum) {
-    const uint32_t P = F.tile_w * F.tile_h;
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= P) return;
-    const uint32_t py = F.tile_y0 + p / F.tile_w, px = F.tile_x0 + p % F.tile_w;
-    float4 acc = accum[(size_t)py * F.width + px];
-    for (uint32_t k = 0; k < F.n_samples; k++) {
-        const float4 c = rad[(size_t)k * P + p];
-        acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
-    }
-    accum[(size_t)py * F.width + px] = acc;
-}
-
-} // namespace
+#include "pathtrace.h"
 
 // ===========================================================================
 // Host side
