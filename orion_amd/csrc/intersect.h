@@ -130,6 +130,11 @@ __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]);
 // ANY = true stops at the first accepted triangle (point-light shadow query,
 // orion/raytracer.cpp:198-199: any hit at t >= 0 on the unbounded ray).
 // ---------------------------------------------------------------------------
+// Keeps a 16-byte load whole and where it was written.  Left alone, the compiler splits a record's
+// loads and sinks the parts into the branches that use them (first the leaf flag, then, inside the
+// branch, the box), which turns one memory round trip per node into two dependent ones.
+__device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 template <bool ANY>
 __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, HitRec& h) {
     const V3 inv = ray_inverse(d);
@@ -137,14 +142,16 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
     uint32_t node = 0;
     const uint32_t n_nodes = S.n_nodes;
     while (node < n_nodes) {
-        const float4 A = reinterpret_cast<const float4*>(S.nodes)[2 * node];
-        const float4 B = reinterpret_cast<const float4*>(S.nodes)[2 * node + 1];
+        float4 A = reinterpret_cast<const float4*>(S.nodes)[2 * node];
+        float4 B = reinterpret_cast<const float4*>(S.nodes)[2 * node + 1];
+        pin(A); pin(B);   // both halves in one round trip (see pin)
         const uint32_t a = __float_as_uint(A.w), b = __float_as_uint(B.w);
         if (b & kLeafFlag) {
             const uint32_t cnt = b & ~kLeafFlag;
             for (uint32_t s = 0; s < cnt; s++) {
                 const float4* tp = reinterpret_cast<const float4*>(S.tris + (a + s));
-                const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+                float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+                pin(T0); pin(T1); pin(T2);
                 bool acc = tri_hit(mk(T0.x, T0.y, T0.z), mk(T1.x, T1.y, T1.z), mk(T2.x, T2.y, T2.z), __float_as_uint(T0.w), o, d, h);
                 if (ANY && acc) return;
             }
