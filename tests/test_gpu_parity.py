@@ -388,3 +388,56 @@ def test_tail_kernel_changes_nothing(gpu, point):
     assert np.isfinite(imgs[0]).all() and imgs[0][:, :, :3].max() > 0
     for im in imgs[1:]:
         assert np.array_equal(bits(im), bits(imgs[0]))
+
+
+def _tie_scene(n_meshes, tris_per_mesh, seed):
+    """Meshes of random triangles in which every third triangle is an exact copy of an earlier one
+    (of the same mesh or of a previous mesh) and quads share their diagonal: rays at them produce
+    exact ties in t, which the reference resolves by visit order."""
+    from orion_amd import host
+    rng = np.random.default_rng(seed)
+    pool, models = [], []
+    for _ in range(n_meshes):
+        tri = []
+        for k in range(tris_per_mesh):
+            if pool and k % 3 == 2:
+                tri.append(pool[rng.integers(len(pool))].copy())
+            elif k % 3 == 1 and tri:
+                a, b, c = tri[-1]
+                tri.append(np.stack([a, c, a + (c - b)]))     # shares the edge a-c with the previous one
+            else:
+                ctr = rng.uniform(-1, 1, 3)
+                tri.append((ctr + rng.normal(scale=0.6, size=(3, 3))).astype(np.float32))
+        tri = np.asarray(tri, np.float32)
+        pool.extend(tri)
+        v = np.zeros((len(tri) * 3, 8), np.float32)
+        v[:, :3] = tri.reshape(-1, 3)
+        v[:, 3:6] = [0, 1, 0]
+        models.append(host.model_from_arrays(v, np.arange(len(v), dtype=np.uint32)))
+    return host.merge_models(models), np.asarray(pool, np.float32)
+
+
+@pytest.mark.parametrize("n_meshes,per_mesh,modes", [(4, 9, (1, 2, 3)), (6, 90, (1, 2))])
+def test_exact_ties_resolve_like_the_reference(gpu, n_meshes, per_mesh, modes):
+    from oracle import bindings as ob
+    model, pool = _tie_scene(n_meshes, per_mesh, seed=31 + per_mesh)
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    # aim at points inside (and on the edges and vertices of) the triangles
+    t = pool[rng.integers(len(pool), size=n)]
+    w = rng.dirichlet([1, 1, 1], size=n).astype(np.float32)
+    w[::7] = [0.5, 0.5, 0.0]; w[::11] = [1.0, 0.0, 0.0]; w[::13] = [0.0, 0.5, 0.5]
+    target = (t * w[:, :, None]).sum(1).astype(np.float32)
+    o = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    oid, otuv = ob.OracleScene(model).closest_hit(o, d, threads=8)
+    assert (oid[:, 0] != gpu.INVALID).mean() > 0.9
+    sc = gpu.Scene(model, device=0)
+    for mode in modes:
+        sc.set_option("traversal", mode)
+        for hs in ((1, 0) if mode == 2 else (1,)):
+            sc.set_option("hand_scheduled", hs)
+            ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+            assert np.array_equal(ids, oid), f"mode {mode} hand_scheduled {hs}: ids"
+            assert np.array_equal(bits(tuv), bits(otuv)), f"mode {mode} hand_scheduled {hs}: t,u,v"
+    sc.close()
