@@ -174,8 +174,6 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *   "tail_paths"  a render batch hands its remaining paths to the one-path-per-wave
  *                 tail kernel once at most this many are left (0 = never; small scenes only)
  *   "batch_paths" upper bound on paths in flight per render batch
- *   "hand_scheduled" 1 (default) = the wave-synchronous closest-hit walk runs its
- *                 hand-scheduled form, 0 = the compiler's form of the same loop
  * Results never depend on these. */
 int orion_hip_scene_set_option(OrionScene* scene, const char* name, int64_t value);
 

@@ -93,7 +93,6 @@ struct SceneView {
     uint32_t n_tris;
     uint32_t n_meshes;
     uint32_t n_emissive;
-    uint32_t hand_scheduled;      // 1: wave-synchronous closest hit through traverse_wave_closest_asm
     const WaveItem* items;        // one-ray-per-wave table, n_items entries (0: the scene is too large for it)
     uint32_t n_items;
 };

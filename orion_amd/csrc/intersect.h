@@ -172,7 +172,7 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
 // paths, which for scenes of a few dozen nodes is close to every lane's own path.
 // Must be entered by all lanes that want a result; `active` = false lanes idle.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next);
+__device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast);
 
 template <bool ANY>
 __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
@@ -180,8 +180,8 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
     const bool fast = __all(!active || slab_safe(o, inv));   // wave-uniform choice of the slab arithmetic
     uint32_t next = active ? 0u : kInvalid;
     const uint32_t n_nodes = S.n_nodes;
-    if (!ANY && fast && n_nodes && S.hand_scheduled) {   // the common case runs the hand-scheduled loop
-        traverse_wave_closest_asm(S, o, d, inv, h, next);
+    if (!ANY) {   // the closest-hit walk is hand-scheduled; the loop below is the any-hit walk
+        if (n_nodes) traverse_wave_closest_asm(S, o, d, inv, h, next, __builtin_amdgcn_readfirstlane(fast ? 1u : 0u));
         return;
     }
     for (uint32_t node = 0; node < n_nodes; node++) {
@@ -308,24 +308,24 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 }
 
 // ---------------------------------------------------------------------------
-// The closest-hit wave walk, hand-scheduled.  Same algorithm and the same FP32
-// operations in the same order as traverse_wave<false> with slab_hit_fast and
-// tri_hit (the division is the compiler's own correctly rounded sequence), but
+// The closest-hit wave walk, hand-scheduled.  The algorithm of traverse_wave
+// and the FP32 operations of slab_hit / slab_hit_fast and tri_hit in the same
+// order (the division is the compiler's own correctly rounded sequence), but
 // with what the compiler will not do for this loop: one scalar pointer that
 // steps through the node array, one 48-byte scalar fetch per triangle, the
 // execution mask narrowed stage by stage with a single restore per triangle,
 // and no register shuffling between loop levels.  The wave spends its time in
 // this loop, one instruction at a time, so its length is the traversal's speed.
-// Preconditions: slab_safe() holds for every active lane (the caller checks it
-// wave-wide), n_nodes > 0 and the scene's triangle array is below 4 GiB (the
+// `fast` (wave-uniform): slab_safe() holds for every active lane, the min/max
+// slab test may be used.  Preconditions: n_nodes > 0 and the scene's triangle array is below 4 GiB (the
 // walk is only chosen for scenes of a few dozen nodes).  SGPRs s64-s75 hold the
 // node or triangle being processed.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next) {
+__device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast) {
     float ht = h.t, hu = h.u, hv = h.v;
     uint32_t hg = h.gtri;
     // VGPR temporaries; the division's five and qvec share registers with values that are dead or not live yet
-    float px, py, pz, det, idet, tx, ty, tz, aa, bb, cc, uu, du, dv, ww, dt;
+    float px, py, pz, det, idet, tx, ty, tz, aa, bb, cc, uu, du, dv, dt;
     // SGPR temporaries: EX = lanes that entered, MI = lanes at the current node, PM = a stage's verdict
     unsigned long long EX, MI, PM;
     uint32_t noff, toff, cnt, node, node1, eps;
@@ -356,6 +356,8 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_mul_f32 %[uu], %[uu], %[iy]\n"
         "v_mul_f32 %[du], %[du], %[iz]\n"
         "v_mul_f32 %[dv], %[dv], %[iz]\n"
+        "s_cmp_eq_u32 %[fast], 0\n"
+        "s_cbranch_scc1 L_slab_exact%=\n"
         "v_min_f32 %[tx], %[aa], %[bb]\n"
         "v_min_f32 %[ty], %[cc], %[uu]\n"
         "v_min_f32 %[tz], %[du], %[dv]\n"
@@ -364,6 +366,22 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_max_f32 %[du], %[du], %[dv]\n"
         "v_max3_f32 %[tx], %[tx], %[ty], %[tz]\n"      // tmin
         "v_min3_f32 %[aa], %[aa], %[cc], %[du]\n"      // tmax
+        "s_branch L_slab_done%=\n"
+        // the reference's select order, for waves with a ray whose products can be NaN:
+        // lx = (t1<t2)?t1:t2, hx = (t1>t2)?t1:t2, tmin = (lx<m)?m:lx with m = (ly<lz)?lz:ly,
+        // tmax = (m2<hx)?m2:hx with m2 = (hz<hy)?hz:hy  (orion/AABB.hpp:79-99, orion/math.hpp:336-365)
+        "L_slab_exact%=:\n"
+        "v_cmp_lt_f32 vcc, %[aa], %[bb]\n s_nop 1\n v_cndmask_b32 %[tx], %[bb], %[aa], vcc\n"
+        "v_cmp_lt_f32 vcc, %[cc], %[uu]\n s_nop 1\n v_cndmask_b32 %[ty], %[uu], %[cc], vcc\n"
+        "v_cmp_lt_f32 vcc, %[du], %[dv]\n s_nop 1\n v_cndmask_b32 %[tz], %[dv], %[du], vcc\n"
+        "v_cmp_gt_f32 vcc, %[aa], %[bb]\n s_nop 1\n v_cndmask_b32 %[aa], %[bb], %[aa], vcc\n"
+        "v_cmp_gt_f32 vcc, %[cc], %[uu]\n s_nop 1\n v_cndmask_b32 %[cc], %[uu], %[cc], vcc\n"
+        "v_cmp_gt_f32 vcc, %[du], %[dv]\n s_nop 1\n v_cndmask_b32 %[du], %[dv], %[du], vcc\n"
+        "v_cmp_lt_f32 vcc, %[ty], %[tz]\n s_nop 1\n v_cndmask_b32 %[ty], %[ty], %[tz], vcc\n"
+        "v_cmp_lt_f32 vcc, %[tx], %[ty]\n s_nop 1\n v_cndmask_b32 %[tx], %[tx], %[ty], vcc\n"
+        "v_cmp_lt_f32 vcc, %[du], %[cc]\n s_nop 1\n v_cndmask_b32 %[cc], %[cc], %[du], vcc\n"
+        "v_cmp_lt_f32 vcc, %[cc], %[aa]\n s_nop 1\n v_cndmask_b32 %[aa], %[aa], %[cc], vcc\n"
+        "L_slab_done%=:\n"
         "v_cmp_gt_f32 vcc, %[aa], %[tx]\n"
         "v_cmp_lt_f32_e64 %[PM], 0, %[aa]\n"
         "v_mov_b32 %[bb], %[node1]\n"
@@ -400,15 +418,15 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_cmp_nlt_f32_e64 %[PM], |%[det]|, %[eps]\n"
         "s_and_b64 exec, exec, %[PM]\n"
         "s_cbranch_scc0 L_tri_next%=\n"
-        // inv_det = 1 / det, correctly rounded (q0 = aa, r = bb, q1 = cc, e = ww, m = dt)
+        // inv_det = 1 / det, correctly rounded (q0 = aa, r = bb, q1 = cc, e = tx, m = dt)
         "v_div_scale_f32 %[aa], %[PM], %[det], %[det], 1.0\n"
         "v_rcp_f32 %[bb], %[aa]\n"
         "v_div_scale_f32 %[cc], vcc, 1.0, %[det], 1.0\n"
-        "v_fma_f32 %[ww], -%[aa], %[bb], 1.0\n"
-        "v_fmac_f32 %[bb], %[ww], %[bb]\n"
+        "v_fma_f32 %[tx], -%[aa], %[bb], 1.0\n"
+        "v_fmac_f32 %[bb], %[tx], %[bb]\n"
         "v_mul_f32 %[dt], %[cc], %[bb]\n"
-        "v_fma_f32 %[ww], -%[aa], %[dt], %[cc]\n"
-        "v_fmac_f32 %[dt], %[ww], %[bb]\n"
+        "v_fma_f32 %[tx], -%[aa], %[dt], %[cc]\n"
+        "v_fmac_f32 %[dt], %[tx], %[bb]\n"
         "v_fma_f32 %[aa], -%[aa], %[dt], %[cc]\n"
         "v_div_fmas_f32 %[aa], %[aa], %[bb], %[dt]\n"
         "v_div_fixup_f32 %[idet], %[aa], %[det], 1.0\n"
@@ -439,9 +457,9 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_mul_f32 %[cc], %[dz], %[pz]\n"
         "v_add_f32 %[aa], %[aa], %[bb]\n"
         "v_add_f32 %[dv], %[aa], %[cc]\n"
-        "v_mul_f32 %[ww], %[dv], %[idet]\n"
-        "v_cmp_ngt_f32 vcc, 0, %[ww]\n"
-        "v_add_f32 %[bb], %[uu], %[ww]\n"
+        "v_mul_f32 %[aa], %[dv], %[idet]\n"
+        "v_cmp_ngt_f32 vcc, 0, %[aa]\n"
+        "v_add_f32 %[bb], %[uu], %[aa]\n"
         "v_cmp_nlt_f32_e64 %[PM], 1.0, %[bb]\n"
         "s_and_b64 %[PM], vcc, %[PM]\n"
         "s_and_b64 exec, exec, %[PM]\n"
@@ -484,12 +502,12 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         : [nx] "+v"(next), [ht] "+v"(ht), [hu] "+v"(hu), [hv] "+v"(hv), [hg] "+v"(hg),
           [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [det] "=&v"(det), [idet] "=&v"(idet),
           [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz),
-          [aa] "=&v"(aa), [bb] "=&v"(bb), [cc] "=&v"(cc), [uu] "=&v"(uu), [du] "=&v"(du), [dv] "=&v"(dv), [ww] "=&v"(ww), [dt] "=&v"(dt),
+          [aa] "=&v"(aa), [bb] "=&v"(bb), [cc] "=&v"(cc), [uu] "=&v"(uu), [du] "=&v"(du), [dv] "=&v"(dv), [dt] "=&v"(dt),
           [EX] "=&s"(EX), [MI] "=&s"(MI), [PM] "=&s"(PM),
           [noff] "=&s"(noff), [toff] "=&s"(toff), [cnt] "=&s"(cnt), [node] "=&s"(node), [node1] "=&s"(node1), [eps] "=&s"(eps)
         : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z),
           [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z),
-          [nodes] "s"(S.nodes), [tris] "s"(S.tris), [nn] "s"(S.n_nodes)
+          [nodes] "s"(S.nodes), [tris] "s"(S.tris), [nn] "s"(S.n_nodes), [fast] "s"(fast)
         : "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "vcc", "scc");
     h.t = ht; h.u = hu; h.v = hv; h.gtri = hg;
 }

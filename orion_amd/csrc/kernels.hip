@@ -440,7 +440,6 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     if ((rc = upload(s, emissive, &v.emissive))) return bail(rc);
     v.n_nodes = (uint32_t)nodes.size(); v.n_tris = (uint32_t)tris.size();
     v.n_meshes = n_meshes; v.n_emissive = (uint32_t)emissive.size();
-    v.hand_scheduled = 1;
     if (!items.empty()) { if ((rc = upload(s, items, &v.items))) return bail(rc); v.n_items = 64; }
     s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
     for (const Mesh& dm : dmeshes) s->mesh_tri_base.push_back(dm.tri_base);
@@ -470,11 +469,6 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
         if (value < 0 || value > 3) return fail(1, "set_option: traversal must be 0, 1, 2 or 3");
         if (value == 3 && s->view.n_items == 0) return fail(1, "set_option: the scene is too large for one ray per wave (more than 64 inner nodes + triangles)");
         s->traversal = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(name, "hand_scheduled")) {
-        if (value < 0 || value > 1) return fail(1, "set_option: hand_scheduled must be 0 or 1");
-        s->view.hand_scheduled = (uint32_t)value;
         return 0;
     }
     if (!std::strcmp(name, "tail_paths")) {
@@ -632,8 +626,8 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                 } else {
                     if (wide) extend(k_extend<MODE, kRaysWide, false>); else extend(k_extend<MODE, 1, false>);
                 }
-                launch(s, ORION_KERNEL_SHADE, 0, point ? k_shade<MODE, true> : k_shade<MODE, false>,
-                       dim3(grid_for(bound)), dim3(kBlock), s->view, F, depth, qb, cnt, d_hits, qa, cnt + 1, d_rad);
+                auto shade = point ? k_shade<MODE, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf : k_shade<MODE, false>);
+                launch(s, ORION_KERNEL_SHADE, 0, shade, dim3(grid_for(bound)), dim3(kBlock), s->view, F, depth, qb, cnt, d_hits, qa, cnt + 1, d_rad);
             });
             HIP_TRY(hipGetLastError());
             launched = depth + 1;

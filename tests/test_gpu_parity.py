@@ -309,34 +309,36 @@ def test_many_emissive_meshes_and_odd_light_samples(gpu):
     sc.close()
 
 
-def test_hand_scheduled_walk_equals_the_compilers(gpu):
-    """The wave-synchronous closest-hit walk exists twice: hand-scheduled assembly and the C++ loop it
-    was derived from.  Same rays in, the same bits out -- ray queries and a rendered image."""
-    import torch
+def test_the_three_walks_agree(gpu):
+    """Per-lane, wave-synchronous (hand-scheduled assembly) and one-ray-per-wave traversal: same rays
+    in, the same bits out -- ray queries, including waves pushed onto the exact-select slab test by
+    rays with zero direction components, and a rendered image."""
     model = conftest.load_model("cornell")
     sc = gpu.Scene(model, device=0)
-    sc.set_option("traversal", 2)
     rng = np.random.default_rng(77)
     n = 1 << 18
     o = rng.uniform(-1.2, 1.2, (n, 3)).astype(np.float32) + np.float32([0, 1, 0])
     d = rng.normal(size=(n, 3)).astype(np.float32)
     d[::97, 0] = 0.0            # rays that push their wave onto the exact-select slab test
+    d[5::131, 1] = 0.0
     o[::1013] = np.float32([0.0, 1.0, 8.0])
     eye, look, up, yv = CORNELL_CAM
     cam = gpu.camera_vectors(eye, look, up, yv, 1.5)
     out = {}
-    for flag in (1, 0):
-        sc.set_option("hand_scheduled", flag)
+    for mode in (1, 2, 3):
+        sc.set_option("traversal", mode)
         h = sc.closest_hit(o, d)
         img = sc.render(cam, 96, 64, 0, 6, 2, 20, seed=3)
-        out[flag] = (h.copy(), img.copy())
+        out[mode] = (h.copy(), img.copy())
     sc.close()
-    a, b = out[1], out[0]
-    assert np.array_equal(a[0]["mesh"], b[0]["mesh"]) and np.array_equal(a[0]["tri"], b[0]["tri"])
-    for f in ("t", "u", "v"):
-        assert np.array_equal(bits(a[0][f]), bits(b[0][f])), f
+    a = out[1]
     assert (a[0]["mesh"] != gpu.INVALID).sum() > n // 2
-    assert np.array_equal(bits(a[1]), bits(b[1]))
+    for mode in (2, 3):
+        b = out[mode]
+        assert np.array_equal(a[0]["mesh"], b[0]["mesh"]) and np.array_equal(a[0]["tri"], b[0]["tri"]), mode
+        for f in ("t", "u", "v"):
+            assert np.array_equal(bits(a[0][f]), bits(b[0][f])), (mode, f)
+        assert np.array_equal(bits(a[1]), bits(b[1])), mode
 
 
 @pytest.mark.parametrize("name", ["cornell", "view_test"])
@@ -435,9 +437,7 @@ def test_exact_ties_resolve_like_the_reference(gpu, n_meshes, per_mesh, modes):
     sc = gpu.Scene(model, device=0)
     for mode in modes:
         sc.set_option("traversal", mode)
-        for hs in ((1, 0) if mode == 2 else (1,)):
-            sc.set_option("hand_scheduled", hs)
-            ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
-            assert np.array_equal(ids, oid), f"mode {mode} hand_scheduled {hs}: ids"
-            assert np.array_equal(bits(tuv), bits(otuv)), f"mode {mode} hand_scheduled {hs}: t,u,v"
+        ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+        assert np.array_equal(ids, oid), f"mode {mode}: ids"
+        assert np.array_equal(bits(tuv), bits(otuv)), f"mode {mode}: t,u,v"
     sc.close()
