@@ -318,7 +318,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 // this loop, one instruction at a time, so its length is the traversal's speed.
 // `fast` (wave-uniform): slab_safe() holds for every active lane, the min/max
 // slab test may be used.  Preconditions: n_nodes > 0 and the scene's triangle array is below 4 GiB (the
-// walk is only chosen for scenes of a few dozen nodes).  SGPRs s64-s75 hold the
+// walk is only chosen for scenes of a few dozen nodes).  SGPRs s52-s63 hold the
 // node or triangle being processed.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast) {
@@ -338,18 +338,18 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_cmp_eq_u32_e64 %[MI], %[node], %[nx]\n"
         "s_cmp_eq_u64 %[MI], 0\n"
         "s_cbranch_scc1 L_next%=\n"
-        "s_load_dwordx8 s[64:71], %[nodes], %[noff]\n" // lo.xyz a | hi.xyz b
+        "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n" // lo.xyz a | hi.xyz b
         "s_add_u32 %[node1], %[node], 1\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "s_bitcmp1_b32 s71, 31\n"
+        "s_bitcmp1_b32 s59, 31\n"
         "s_cbranch_scc1 L_leaf%=\n"
         // ---- inner node: slab test, next = in ? node + 1 : skip
-        "v_sub_f32 %[aa], s64, %[ox]\n"
-        "v_sub_f32 %[bb], s68, %[ox]\n"
-        "v_sub_f32 %[cc], s65, %[oy]\n"
-        "v_sub_f32 %[uu], s69, %[oy]\n"
-        "v_sub_f32 %[du], s66, %[oz]\n"
-        "v_sub_f32 %[dv], s70, %[oz]\n"
+        "v_sub_f32 %[aa], s52, %[ox]\n"
+        "v_sub_f32 %[bb], s56, %[ox]\n"
+        "v_sub_f32 %[cc], s53, %[oy]\n"
+        "v_sub_f32 %[uu], s57, %[oy]\n"
+        "v_sub_f32 %[du], s54, %[oz]\n"
+        "v_sub_f32 %[dv], s58, %[oz]\n"
         "v_mul_f32 %[aa], %[aa], %[ix]\n"
         "v_mul_f32 %[bb], %[bb], %[ix]\n"
         "v_mul_f32 %[cc], %[cc], %[iy]\n"
@@ -385,34 +385,34 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_cmp_gt_f32 vcc, %[aa], %[tx]\n"
         "v_cmp_lt_f32_e64 %[PM], 0, %[aa]\n"
         "v_mov_b32 %[bb], %[node1]\n"
-        "v_mov_b32 %[cc], s67\n"
+        "v_mov_b32 %[cc], s55\n"
         "s_and_b64 vcc, vcc, %[PM]\n"
         "v_cndmask_b32_e32 %[bb], %[cc], %[bb], vcc\n"
         "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"
         "s_branch L_next%=\n"
         // ---- leaf: its triangles, for the lanes that are here
         "L_leaf%=:\n"
-        "s_and_b32 %[cnt], s71, 0x7fffffff\n"          // triangle count
+        "s_and_b32 %[cnt], s59, 0x7fffffff\n"          // triangle count
         "s_cbranch_scc0 L_leaf_done%=\n"
-        "s_mul_i32 %[toff], s67, 48\n"                 // byte offset of the leaf's first triangle
+        "s_mul_i32 %[toff], s55, 48\n"                 // byte offset of the leaf's first triangle
         "s_and_b64 exec, %[EX], %[MI]\n"
         "L_tri%=:\n"
-        "s_load_dwordx4 s[64:67], %[tris], %[toff]\n"              // v0.xyz gtri
-        "s_load_dwordx4 s[68:71], %[tris], %[toff] offset:0x10\n"  // e1.xyz
-        "s_load_dwordx4 s[72:75], %[tris], %[toff] offset:0x20\n"  // e2.xyz
+        "s_load_dwordx4 s[52:55], %[tris], %[toff]\n"              // v0.xyz gtri
+        "s_load_dwordx4 s[56:59], %[tris], %[toff] offset:0x10\n"  // e1.xyz
+        "s_load_dwordx4 s[60:63], %[tris], %[toff] offset:0x20\n"  // e2.xyz
         "s_add_u32 %[toff], %[toff], 48\n"
         "s_waitcnt lgkmcnt(0)\n"
         // pvec = cross(d, e2)
-        "v_mul_f32 %[px], s74, %[dy]\n"
-        "v_mul_f32 %[py], s72, %[dz]\n"
-        "v_mul_f32 %[pz], s73, %[dx]\n"
-        "v_fma_f32 %[px], -%[dz], s73, %[px]\n"
-        "v_fma_f32 %[py], -%[dx], s74, %[py]\n"
-        "v_fma_f32 %[pz], -%[dy], s72, %[pz]\n"
+        "v_mul_f32 %[px], s62, %[dy]\n"
+        "v_mul_f32 %[py], s60, %[dz]\n"
+        "v_mul_f32 %[pz], s61, %[dx]\n"
+        "v_fma_f32 %[px], -%[dz], s61, %[px]\n"
+        "v_fma_f32 %[py], -%[dx], s62, %[py]\n"
+        "v_fma_f32 %[pz], -%[dy], s60, %[pz]\n"
         // det = dot(e1, pvec)
-        "v_mul_f32 %[aa], s68, %[px]\n"
-        "v_mul_f32 %[bb], s69, %[py]\n"
-        "v_mul_f32 %[cc], s70, %[pz]\n"
+        "v_mul_f32 %[aa], s56, %[px]\n"
+        "v_mul_f32 %[bb], s57, %[py]\n"
+        "v_mul_f32 %[cc], s58, %[pz]\n"
         "v_add_f32 %[aa], %[aa], %[bb]\n"
         "v_add_f32 %[det], %[aa], %[cc]\n"
         "v_cmp_nlt_f32_e64 %[PM], |%[det]|, %[eps]\n"
@@ -431,9 +431,9 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_div_fmas_f32 %[aa], %[aa], %[bb], %[dt]\n"
         "v_div_fixup_f32 %[idet], %[aa], %[det], 1.0\n"
         // tvec = o - v0, u = dot(tvec, pvec) * inv_det
-        "v_subrev_f32 %[tx], s64, %[ox]\n"
-        "v_subrev_f32 %[ty], s65, %[oy]\n"
-        "v_subrev_f32 %[tz], s66, %[oz]\n"
+        "v_subrev_f32 %[tx], s52, %[ox]\n"
+        "v_subrev_f32 %[ty], s53, %[oy]\n"
+        "v_subrev_f32 %[tz], s54, %[oz]\n"
         "v_mul_f32 %[aa], %[tx], %[px]\n"
         "v_mul_f32 %[bb], %[ty], %[py]\n"
         "v_mul_f32 %[cc], %[tz], %[pz]\n"
@@ -446,12 +446,12 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "s_and_b64 exec, exec, %[PM]\n"
         "s_cbranch_scc0 L_tri_next%=\n"
         // qvec = cross(tvec, e1) (in pvec's registers), v = dot(d, qvec) * inv_det
-        "v_mul_f32 %[px], s70, %[ty]\n"
-        "v_mul_f32 %[py], s68, %[tz]\n"
-        "v_mul_f32 %[pz], s69, %[tx]\n"
-        "v_fma_f32 %[px], -%[tz], s69, %[px]\n"
-        "v_fma_f32 %[py], -%[tx], s70, %[py]\n"
-        "v_fma_f32 %[pz], -%[ty], s68, %[pz]\n"
+        "v_mul_f32 %[px], s58, %[ty]\n"
+        "v_mul_f32 %[py], s56, %[tz]\n"
+        "v_mul_f32 %[pz], s57, %[tx]\n"
+        "v_fma_f32 %[px], -%[tz], s57, %[px]\n"
+        "v_fma_f32 %[py], -%[tx], s58, %[py]\n"
+        "v_fma_f32 %[pz], -%[ty], s56, %[pz]\n"
         "v_mul_f32 %[aa], %[dx], %[px]\n"
         "v_mul_f32 %[bb], %[dy], %[py]\n"
         "v_mul_f32 %[cc], %[dz], %[pz]\n"
@@ -465,9 +465,9 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "s_and_b64 exec, exec, %[PM]\n"
         "s_cbranch_scc0 L_tri_next%=\n"
         // t = dot(e2, qvec) * inv_det
-        "v_mul_f32 %[aa], s72, %[px]\n"
-        "v_mul_f32 %[bb], s73, %[py]\n"
-        "v_mul_f32 %[cc], s74, %[pz]\n"
+        "v_mul_f32 %[aa], s60, %[px]\n"
+        "v_mul_f32 %[bb], s61, %[py]\n"
+        "v_mul_f32 %[cc], s62, %[pz]\n"
         "v_add_f32 %[aa], %[aa], %[bb]\n"
         "v_add_f32 %[dt], %[aa], %[cc]\n"
         "v_mul_f32 %[bb], %[dt], %[idet]\n"
@@ -483,7 +483,7 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         "v_mul_f32 %[hu], %[aa], %[idet]\n"
         "v_mul_f32 %[hv], %[cc], %[idet]\n"
         "v_mul_f32 %[ht], %[bb], %[idet]\n"
-        "v_mov_b32 %[hg], s67\n"
+        "v_mov_b32 %[hg], s55\n"
         "L_tri_next%=:\n"
         "s_and_b64 exec, %[EX], %[MI]\n"
         "s_sub_u32 %[cnt], %[cnt], 1\n"
@@ -508,7 +508,7 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
         : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z),
           [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z),
           [nodes] "s"(S.nodes), [tris] "s"(S.tris), [nn] "s"(S.n_nodes), [fast] "s"(fast)
-        : "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "vcc", "scc");
+        : "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc");
     h.t = ht; h.u = hu; h.v = hv; h.gtri = hg;
 }
 
