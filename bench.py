@@ -182,8 +182,8 @@ def main():
                                "note": "achieved = algorithmic bytes per launch / average launch duration (HIP events on the "
                                        "library's stream over the timed region); traffic = HBM bytes per launch from the PMC passes "
                                        "in profiles/ (FETCH_SIZE doubled per the gfx950 correction). The kernel is bound by "
-                                       "instruction issue (one instruction per ~3 cycles per SIMD, the chip's measured "
-                                       "sustained rate), not by HBM."}
+                                       "instruction issue (one VALU instruction per 3.2 cycles per SIMD against a measured "
+                                       "sustained 2.84), not by HBM."}
             out["kernels"] = kern
             rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
             out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
