@@ -251,6 +251,24 @@ def load_image(path: str) -> Texture:
     return Texture(np.ascontiguousarray(a))
 
 
+def load_png(path: str) -> Texture:
+    """Decode a PNG with the C++ host layer's own reader (what the orion_rt tool uses); raises on failure."""
+    L = lib()
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    buf = C.POINTER(C.c_uint8)()
+    err = C.create_string_buffer(256)
+    L.orion_host_load_png.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.POINTER(C.c_uint8)), C.c_char_p, C.c_int]
+    L.orion_host_free.argtypes = [C.c_void_p]
+    if L.orion_host_load_png(path.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(buf), err, 256) != 0:
+        raise RuntimeError(f"{path}: {err.value.decode()}")
+    try:
+        a = np.ctypeslib.as_array(buf, shape=(h.value, w.value, c.value)).copy()
+    finally:
+        L.orion_host_free(buf)
+    return Texture(a)
+
+
 def model_from_arrays(vertices: np.ndarray, indices: np.ndarray, strategy: int = MEDIAN,
                       material: Optional[Material] = None) -> Model:
     """One-mesh model from caller arrays (synthetic scenes)."""

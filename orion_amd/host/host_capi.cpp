@@ -1,5 +1,6 @@
 // C entry points over the host layer for scripting (ctypes): scene files in,
 // flat arrays out.  No GPU code here.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -107,5 +108,20 @@ const char* orion_host_material_string(void* h, uint32_t mat, int which) {
     default: return m.map_ambient.c_str();
     }
 }
+
+// PNG texture decode (png_reader.cpp).  Returns 0 and a malloc'd buffer of width*height*channels
+// bytes (release with orion_host_free), or -1 with a message in err (up to err_len bytes).
+int orion_host_load_png(const char* path, int* width, int* height, int* channels, uint8_t** texels, char* err, int err_len) {
+    std::vector<uint8_t> data;
+    std::string e;
+    if (!load_png(path, *width, *height, *channels, data, e)) {
+        if (err && err_len > 0) { std::strncpy(err, e.c_str(), (size_t)err_len - 1); err[err_len - 1] = 0; }
+        return -1;
+    }
+    *texels = static_cast<uint8_t*>(std::malloc(data.size()));
+    std::memcpy(*texels, data.data(), data.size());
+    return 0;
+}
+void orion_host_free(void* p) { std::free(p); }
 
 } // extern "C"

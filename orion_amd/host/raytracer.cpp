@@ -50,14 +50,23 @@ struct TexturePool {
     // returns false when the file cannot be used; the caller falls back to the solid colour
     bool add_image(const std::string& path, uint32_t& out) {
         for (auto& kv : loaded) if (kv.first == path) { out = kv.second; return true; }
-        int w = 0, h = 0;
-        std::vector<uint8_t> rgb;
-        if (!ends_with(path, ".ppm") || !load_ppm(path, w, h, rgb)) {
-            std::fprintf(stderr, "texture %s: only binary PPM images are decoded by this tool; using the solid colour\n", path.c_str());
+        int w = 0, h = 0, ch = 3;
+        std::vector<uint8_t> texels;
+        if (ends_with(path, ".ppm")) {
+            if (!load_ppm(path, w, h, texels)) { std::fprintf(stderr, "texture %s: not a binary PPM; using the solid colour\n", path.c_str()); return false; }
+        } else if (ends_with(path, ".png")) {
+            std::string err;
+            if (!load_png(path, w, h, ch, texels, err)) { std::fprintf(stderr, "texture %s: %s; using the solid colour\n", path.c_str(), err.c_str()); return false; }
+            if (ch == 2) {   // the reference refuses two-channel images (orion/texture.hpp:39-42)
+                std::fprintf(stderr, "Unknown texture format (2 color channels) in path: %s\n", path.c_str());
+                return false;
+            }
+        } else {
+            std::fprintf(stderr, "texture %s: this tool decodes PNG and binary PPM images; using the solid colour\n", path.c_str());
             return false;
         }
-        images.push_back(std::move(rgb));
-        descs.push_back({(uint32_t)w, (uint32_t)h, ORION_TEX_RGB_U8, nullptr});
+        images.push_back(std::move(texels));
+        descs.push_back({(uint32_t)w, (uint32_t)h, uint32_t(ch == 1 ? ORION_TEX_GRAY_U8 : ch == 4 ? ORION_TEX_RGBA_U8 : ORION_TEX_RGB_U8), nullptr});
         out = (uint32_t)descs.size() - 1;
         loaded.emplace_back(path, out);
         return true;

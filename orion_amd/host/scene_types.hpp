@@ -88,4 +88,7 @@ struct RtcData {
     std::string texture_file;
 };
 
+// png_reader.cpp: 8-bit texels with the file's channel count (1, 2, 3 or 4), as stbi_load(..., 0) returns them.
+bool load_png(const std::string& path, int& width, int& height, int& channels, std::vector<uint8_t>& out, std::string& err);
+
 } // namespace orion_amd

@@ -58,3 +58,39 @@ def test_cli_renders_derived_rtc(tmp_path):
     from PIL import Image
     png = np.asarray(Image.open(tmp_path / "a.png"))
     assert png.shape == (48, 64, 4) and png[:, :, 3].min() == 255 and png[:, :, :3].max() == 255
+
+
+def test_cli_decodes_png_textures(tmp_path):
+    """view_test scene with its map as an RGBA PNG: the C++ tool decodes it itself and renders the
+    same pixels as the Python binding with the Pillow-decoded image."""
+    from PIL import Image
+    from orion_amd import api, host
+    rng = np.random.default_rng(4)
+    tex = rng.integers(0, 256, (64, 64, 4), dtype=np.uint8)
+    Image.fromarray(tex, "RGBA").save(tmp_path / "map.png")
+    obj = open(os.path.join(conftest.ASSETS, "view_test.obj")).read()
+    mtl = open(os.path.join(conftest.ASSETS, "view_test.mtl")).read()
+    import re
+    mtl = re.sub(r"(?m)^\s*map_\S+.*$", "", mtl)
+    mtl, n = re.subn(r"(?m)^(\s*Kd .*)$", r"\1\n\tmap_Kd map.png", mtl)
+    assert n >= 1
+    (tmp_path / "view_test.obj").write_text(obj)
+    (tmp_path / "view_test.mtl").write_text(mtl)
+    r = host.parse_rtc(os.path.join(conftest.ASSETS, "view_test.rtc"))
+    r.obj_file = "view_test.obj"
+    r.xres, r.yres, r.aspect_ratio, r.recursion_level = 80, 60, 80 / 60, 1
+    rtc_path = str(tmp_path / "vt.rtc")
+    host.write_rtc(rtc_path, r)
+    out = str(tmp_path / "vt.ppm")
+    p = subprocess.run([CLI, rtc_path, "-o", out, "-p", "4", "-l", "1", "--seed", "2"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "solid colour" not in p.stderr, p.stderr
+    img = read_ppm(out)
+    fr = api.load_frame(rtc_path, load_textures=True)
+    assert any(m.tex_diffuse is not None and m.tex_diffuse.data.shape == (64, 64, 4) for m in fr.model.materials)
+    sc = api.Scene(fr.model, device=0)
+    acc = sc.render(fr.camera12, 80, 60, 0, 4, 1, 1, seed=2, lights=fr.rtc.lights)
+    sc.close()
+    want = (np.minimum(1.0, acc[:, :, :3] * np.float32(0.25)) * 255).astype(np.uint8)
+    assert (np.abs(img.astype(int) - want.astype(int)) <= 1).all() and (img == want).mean() > 0.99
+    assert img.std() > 5   # the noise texture is visible

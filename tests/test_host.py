@@ -103,3 +103,53 @@ def test_c_abi_exports_every_declared_symbol():
     # argument validation works without touching a device
     assert L.orion_hip_closest_hit(None, None, None, 1, None) != 0
     assert b"scene is null" in L.orion_hip_last_error()
+
+
+def test_png_reader_matches_pillow(tmp_path):
+    """The C++ host layer's PNG reader against Pillow on every kind of PNG a material map can be:
+    grey, grey+alpha, RGB, RGBA, palette (with and without transparency), 1/2/4-bit, 16-bit, every
+    row filter (Pillow picks them adaptively on noisy data), odd widths."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    w, h = 37, 23
+    noise = lambda c: rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    smooth = (np.add.outer(np.arange(h), np.arange(w)) * 3 % 256).astype(np.uint8)
+    cases = {
+        "L": Image.fromarray(noise(1)[:, :, 0], "L"),
+        "L_smooth": Image.fromarray(smooth, "L"),
+        "LA": Image.fromarray(noise(2), "LA"),
+        "RGB": Image.fromarray(noise(3), "RGB"),
+        "RGB_smooth": Image.fromarray(np.stack([smooth, smooth[::-1], smooth.T[:h, :w] if smooth.T.shape == smooth.shape else smooth], 2), "RGB"),
+        "RGBA": Image.fromarray(noise(4), "RGBA"),
+        "P": Image.fromarray(noise(3), "RGB").quantize(200),
+        "P16": Image.fromarray(noise(3), "RGB").quantize(16),     # 4-bit indices
+        "P2": Image.fromarray(noise(3), "RGB").quantize(2),       # 1-bit indices
+        "1": Image.fromarray(noise(1)[:, :, 0] > 127),            # 1-bit grey
+        "I16": Image.fromarray((rng.integers(0, 65536, (h, w))).astype(np.uint16)),
+    }
+    for name, im in cases.items():
+        path = str(tmp_path / f"{name}.png")
+        extra = {}
+        if name == "P":
+            extra["transparency"] = bytes(rng.integers(0, 256, 200, dtype=np.uint8))
+        im.save(path, **extra)
+        got = host.load_png(path).data
+        back = Image.open(path)
+        if back.mode == "P":
+            want = np.asarray(back.convert("RGBA" if "transparency" in back.info else "RGB"))
+        elif back.mode == "1":
+            want = np.asarray(back, np.uint8)[:, :, None] * 255
+        elif back.mode.startswith("I"):
+            want = (np.asarray(back).astype(np.uint32) >> 8).astype(np.uint8)[:, :, None]   # stb keeps the high byte
+        else:
+            want = np.asarray(back)
+            if want.ndim == 2:
+                want = want[:, :, None]
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        assert np.array_equal(got, want), name
+    with pytest.raises(RuntimeError):
+        host.load_png(str(tmp_path / "missing.png"))
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not a png at all, but long enough to get past the size check........")
+    with pytest.raises(RuntimeError, match="not a PNG"):
+        host.load_png(str(bad))
