@@ -299,4 +299,17 @@ void ref_camera_vectors(const float* eye, const float* lookat, const float* up, 
 
 int ref_max_threads() { return omp_get_max_threads(); }
 
+// The reference's own image decoder (its vendored stb_image, as orion/texture.hpp:34 calls it):
+// 8-bit texels with the file's channel count.  out must hold width*height*4 bytes at most; returns
+// 0 on success, -1 if the decoder refuses the file.
+int ref_load_image(const char* path, int* width, int* height, int* channels, unsigned char* out, size_t out_cap) {
+    unsigned char* raw = stbi_load(path, width, height, channels, 0);
+    if (!raw) return -1;
+    const size_t n = (size_t)*width * *height * *channels;
+    int rc = 0;
+    if (n <= out_cap) std::memcpy(out, raw, n); else rc = -1;
+    stbi_image_free(raw);
+    return rc;
+}
+
 } // extern "C"

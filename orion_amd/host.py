@@ -240,7 +240,19 @@ def load_model(obj_path: str, strategy: int = MEDIAN, load_textures: bool = Fals
 
 
 def load_image(path: str) -> Texture:
-    """Decode an image to uint8 texels, keeping 1, 3 or 4 channels (orion/texture.hpp:33-70)."""
+    """Decode an image to uint8 texels, keeping 1, 3 or 4 channels (orion/texture.hpp:33-70).  PNG and
+    baseline JPEG go through the host layer's own readers (the reference's texels, bit for bit);
+    anything they refuse, and every other format, goes through Pillow."""
+    low = path.lower()
+    try:
+        if low.endswith(".png"):
+            t = load_png(path)
+            if t.data.shape[2] != 2:
+                return t
+        elif low.endswith((".jpg", ".jpeg")):
+            return load_jpeg(path)
+    except RuntimeError:
+        pass
     from PIL import Image
     im = Image.open(path)
     if im.mode not in ("L", "RGB", "RGBA"):
@@ -251,22 +263,32 @@ def load_image(path: str) -> Texture:
     return Texture(np.ascontiguousarray(a))
 
 
-def load_png(path: str) -> Texture:
-    """Decode a PNG with the C++ host layer's own reader (what the orion_rt tool uses); raises on failure."""
+def _load_native(kind: int, path: str) -> Texture:
     L = lib()
     w, h, c = C.c_int(), C.c_int(), C.c_int()
     buf = C.POINTER(C.c_uint8)()
     err = C.create_string_buffer(256)
-    L.orion_host_load_png.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                      C.POINTER(C.POINTER(C.c_uint8)), C.c_char_p, C.c_int]
+    L.orion_host_load_image.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.POINTER(C.c_uint8)), C.c_char_p, C.c_int]
     L.orion_host_free.argtypes = [C.c_void_p]
-    if L.orion_host_load_png(path.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(buf), err, 256) != 0:
+    if L.orion_host_load_image(kind, path.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(buf), err, 256) != 0:
         raise RuntimeError(f"{path}: {err.value.decode()}")
     try:
         a = np.ctypeslib.as_array(buf, shape=(h.value, w.value, c.value)).copy()
     finally:
         L.orion_host_free(buf)
     return Texture(a)
+
+
+def load_png(path: str) -> Texture:
+    """Decode a PNG with the C++ host layer's own reader (what the orion_rt tool uses); raises on failure."""
+    return _load_native(0, path)
+
+
+def load_jpeg(path: str) -> Texture:
+    """Decode a baseline JPEG with the C++ host layer's reader, which follows the arithmetic of the
+    decoder the reference uses (texels identical to the reference's); raises on failure."""
+    return _load_native(1, path)
 
 
 def model_from_arrays(vertices: np.ndarray, indices: np.ndarray, strategy: int = MEDIAN,

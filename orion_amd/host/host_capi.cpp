@@ -109,12 +109,14 @@ const char* orion_host_material_string(void* h, uint32_t mat, int which) {
     }
 }
 
-// PNG texture decode (png_reader.cpp).  Returns 0 and a malloc'd buffer of width*height*channels
-// bytes (release with orion_host_free), or -1 with a message in err (up to err_len bytes).
-int orion_host_load_png(const char* path, int* width, int* height, int* channels, uint8_t** texels, char* err, int err_len) {
+// Texture decode (png_reader.cpp, jpeg_reader.cpp; kind 0 = PNG, 1 = JPEG).  Returns 0 and a malloc'd
+// buffer of width*height*channels bytes (release with orion_host_free), or -1 with a message in
+// err (up to err_len bytes).
+int orion_host_load_image(int kind, const char* path, int* width, int* height, int* channels, uint8_t** texels, char* err, int err_len) {
     std::vector<uint8_t> data;
     std::string e;
-    if (!load_png(path, *width, *height, *channels, data, e)) {
+    const bool ok = kind == 0 ? load_png(path, *width, *height, *channels, data, e) : load_jpeg(path, *width, *height, *channels, data, e);
+    if (!ok) {
         if (err && err_len > 0) { std::strncpy(err, e.c_str(), (size_t)err_len - 1); err[err_len - 1] = 0; }
         return -1;
     }

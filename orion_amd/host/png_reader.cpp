@@ -59,6 +59,7 @@ bool load_png(const std::string& path, int& width, int& height, int& channels, s
         pos += 12 + (size_t)len;
     }
     if (ctype < 0 || w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24)) { err = "missing or bad IHDR"; return false; }
+    if ((uint64_t)w * h > (1u << 27)) { err = "image too large"; return false; }
     if (interlace) { err = "interlaced PNG is not supported"; return false; }
     int src_ch;
     switch (ctype) {

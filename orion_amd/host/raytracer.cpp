@@ -61,8 +61,11 @@ struct TexturePool {
                 std::fprintf(stderr, "Unknown texture format (2 color channels) in path: %s\n", path.c_str());
                 return false;
             }
+        } else if (ends_with(path, ".jpg") || ends_with(path, ".jpeg")) {
+            std::string err;
+            if (!load_jpeg(path, w, h, ch, texels, err)) { std::fprintf(stderr, "texture %s: %s; using the solid colour\n", path.c_str(), err.c_str()); return false; }
         } else {
-            std::fprintf(stderr, "texture %s: this tool decodes PNG and binary PPM images; using the solid colour\n", path.c_str());
+            std::fprintf(stderr, "texture %s: this tool decodes PNG, baseline JPEG and binary PPM images; using the solid colour\n", path.c_str());
             return false;
         }
         images.push_back(std::move(texels));

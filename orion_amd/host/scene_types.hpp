@@ -90,5 +90,7 @@ struct RtcData {
 
 // png_reader.cpp: 8-bit texels with the file's channel count (1, 2, 3 or 4), as stbi_load(..., 0) returns them.
 bool load_png(const std::string& path, int& width, int& height, int& channels, std::vector<uint8_t>& out, std::string& err);
+// jpeg_reader.cpp: baseline JPEG with stb_image's arithmetic; 1 (greyscale) or 3 channels.
+bool load_jpeg(const std::string& path, int& width, int& height, int& channels, std::vector<uint8_t>& out, std::string& err);
 
 } // namespace orion_amd

@@ -153,3 +153,36 @@ def test_png_reader_matches_pillow(tmp_path):
     bad.write_bytes(b"not a png at all, but long enough to get past the size check........")
     with pytest.raises(RuntimeError, match="not a PNG"):
         host.load_png(str(bad))
+
+
+def test_image_readers_match_the_references_decoder(tmp_path):
+    """PNG and baseline-JPEG readers of the host layer against texels the reference's own decoder
+    (its vendored stb_image, run through oracle/_ref when the fixtures were made) returned for the
+    same files: identical bytes, JPEG included (same IDCT, upsampling and colour arithmetic)."""
+    g = np.load(os.path.join(conftest.GOLDEN, "images_stb.npz"))
+    names = sorted(k[:-5] for k in g.files if k.endswith("_file"))
+    assert len(names) >= 30 and any(n.startswith("jpg_restart") for n in names) and "jpg_view_test" in names
+    for n in names:
+        kind = n[:3]
+        path = str(tmp_path / f"x.{kind}")
+        with open(path, "wb") as f:
+            f.write(g[n + "_file"].tobytes())
+        got = (host.load_png if kind == "png" else host.load_jpeg)(path).data
+        want = g[n + "_texels"]
+        assert got.shape == want.shape, (n, got.shape, want.shape)
+        assert np.array_equal(got, want), n
+
+
+def test_jpeg_reader_refuses_what_it_cannot_decode(tmp_path):
+    from PIL import Image
+    im = Image.fromarray(np.random.default_rng(1).integers(0, 256, (16, 16, 3), dtype=np.uint8), "RGB")
+    p = str(tmp_path / "prog.jpg")
+    im.save(p, "JPEG", progressive=True)
+    with pytest.raises(RuntimeError, match="progressive"):
+        host.load_jpeg(p)
+    t = host.load_image(p)          # the general loader falls back to Pillow for it
+    assert t.data.shape == (16, 16, 3)
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"\xff\xd8\xff\xda\x00\x08\x01\x01\x00\x00\x3f\x00garbage")
+    with pytest.raises(RuntimeError):
+        host.load_jpeg(str(bad))
