@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--spp-per-step", type=int, default=128, help="samples per pixel per rank per step (32 = one 64 Mi-path batch at FHD)")
     ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
     ap.add_argument("--tail-paths", type=int, default=-1, help="override the library's tail hand-over threshold (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
