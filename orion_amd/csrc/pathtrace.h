@@ -124,21 +124,66 @@ __device__ __forceinline__ void path_pixel(const FrameParams& F, uint32_t pid, u
     sample = F.spp_begin + k;
 }
 
-// Primary ray of path `pid` as its three queue records (orion/raytracer.cpp:53-72).
-__device__ __forceinline__ void primary_ray(const FrameParams& F, uint32_t pid, float4& qo, float4& qd, float4& qT) {
-    uint32_t pixel, sample, px, py;
-    path_pixel(F, pid, pixel, sample, px, py);
-    // per-sample jitter shared by all pixels (orion/raytracer.cpp:53-63)
+// Per-sample jitter shared by all pixels (orion/raytracer.cpp:53-63).
+__device__ __forceinline__ void sample_jitter(const FrameParams& F, uint32_t sample, float& jx, float& jy) {
     const Words4 r = philox4x32_10(kPatternPixel, sample, 0u, kBlockPattern, F.seed_lo, F.seed_hi);
     const float pixelX = 2.0f / (float)F.width, pixelY = 2.0f / (float)F.height;
-    const float jx = pixelX * u01(r.w[0]), jy = pixelY * u01(r.w[1]);
+    jx = pixelX * u01(r.w[0]); jy = pixelY * u01(r.w[1]);
+}
+
+// Primary ray through pixel (px, py) with the sample's jitter, as its three queue records
+// (orion/raytracer.cpp:64-72).
+__device__ __forceinline__ void primary_ray_at(const FrameParams& F, uint32_t pid, uint32_t px, uint32_t py, uint32_t sample,
+                                               float jx, float jy, float4& qo, float4& qd, float4& qT) {
     const float x = 2 * ((float)px / (float)F.width) - 1;
     const float y = 2 * ((float)py / (float)F.height) - 1;
     const float xs = x + jx, ys = -(y + jy);
     const V3 dir = (ld3(F.front) + ld3(F.right) * xs) + ld3(F.up) * ys;
     qo = make_float4(F.eye[0], F.eye[1], F.eye[2], __uint_as_float(pid));
-    qd = make_float4(dir.x, dir.y, dir.z, __uint_as_float(pixel));
+    qd = make_float4(dir.x, dir.y, dir.z, __uint_as_float(py * F.width + px));
     qT = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
+}
+
+// Primary ray of path `pid`, the general way: three integer divisions and one Philox block.
+__device__ __forceinline__ void primary_ray(const FrameParams& F, uint32_t pid, float4& qo, float4& qd, float4& qT) {
+    uint32_t pixel, sample, px, py;
+    path_pixel(F, pid, pixel, sample, px, py);
+    float jx, jy;
+    sample_jitter(F, sample, jx, jy);
+    primary_ray_at(F, pid, px, py, sample, jx, jy, qo, qd, qT);
+}
+
+// The same for a tile of consecutive path ids that lies inside one sample (all but one tile in
+// two thousand at 1920x1080): the sample, its jitter and the tile's first pixel are found once
+// per block, and a path's pixel is the tile's first pixel plus its slot -- one exact
+// float-reciprocal division with a fix-up instead of three integer divisions and a Philox block
+// per ray, which were a third of the first bounce's instructions.
+struct TileGen {
+    bool fast;             // the tile lies inside one sample
+    uint32_t sample, x0, y0;
+    float jx, jy, inv_w;
+};
+__device__ __forceinline__ TileGen tile_gen(const FrameParams& F, uint32_t tile0, uint32_t tile_size) {
+    TileGen g{};
+    const uint32_t P = F.tile_w * F.tile_h;
+    const uint32_t k = tile0 / P, p0 = tile0 - k * P;
+    g.fast = p0 + tile_size <= P && F.tile_w + tile_size < (1u << 24);
+    if (g.fast) {
+        g.sample = F.spp_begin + k;
+        g.y0 = p0 / F.tile_w; g.x0 = p0 - g.y0 * F.tile_w;
+        g.inv_w = 1.0f / (float)F.tile_w;
+        sample_jitter(F, g.sample, g.jx, g.jy);
+    }
+    return g;
+}
+__device__ __forceinline__ void primary_ray_tile(const FrameParams& F, const TileGen& g, uint32_t pid, uint32_t slot,
+                                                 float4& qo, float4& qd, float4& qT) {
+    if (!g.fast) { primary_ray(F, pid, qo, qd, qT); return; }
+    const uint32_t xt = g.x0 + slot;                       // < 2^24: exact as a float
+    uint32_t q = (uint32_t)((float)xt * g.inv_w);          // floor(xt / tile_w) or one off
+    int32_t r = (int32_t)(xt - q * F.tile_w);
+    if (r < 0) { q--; r += (int32_t)F.tile_w; } else if (r >= (int32_t)F.tile_w) { q++; r -= (int32_t)F.tile_w; }
+    primary_ray_at(F, pid, F.tile_x0 + (uint32_t)r, F.tile_y0 + g.y0 + q, g.sample, g.jx, g.jy, qo, qd, qT);
 }
 
 // Rays per thread of k_extend: kRaysWide while the queue is long (larger tiles group better and
@@ -200,6 +245,8 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
     };
     if (tile0 >= n) { housekeeping(); return; }
     if (threadIdx.x < kMaxBins) s_cnt[threadIdx.x] = 0;
+    TileGen gen{};
+    if (GEN) gen = tile_gen(F, tile0, kTile);
     __syncthreads();
     for (uint32_t k = 0; k < kRaysPerThread; k++) {
         const uint32_t slot = k * kBlock + threadIdx.x;
@@ -208,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
         V3 o = splat(0.0f), d = splat(1.0f);
         if (active) {
             float4 a, b, c;
-            if (GEN) primary_ray(F, i, a, b, c);
+            if (GEN) primary_ray_tile(F, gen, i, slot, a, b, c);
             else { a = qin.o[i]; b = qin.d[i]; }
             o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
         }
@@ -242,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
             const uint32_t i = tile0 + slot;
             const uint32_t dst = base + s_off[min(gtri, n_bins - 1u)] + s_rank[slot];
             float4 a, b, c;
-            if (GEN) primary_ray(F, i, a, b, c);
+            if (GEN) primary_ray_tile(F, gen, i, slot, a, b, c);
             else { a = qin.o[i]; b = qin.d[i]; c = qin.T[i]; }
             qout.o[dst] = a;
             qout.d[dst] = b;
