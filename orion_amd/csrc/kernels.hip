@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -196,13 +197,17 @@ struct Flattener {
 // the tag turning up.
 int await_counters(OrionScene* s, const unsigned long long* slot, uint32_t tag, uint32_t out[2]) {
     const volatile unsigned long long* v = slot;
+    const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spin = 0;; spin++) {
         const unsigned long long a = v[0], b = v[1];
         if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) { out[0] = (uint32_t)a; out[1] = (uint32_t)b; return 0; }
         for (int k = 0; k < 32; k++) __builtin_ia32_pause();   // poll gently: the device's store has to win the line
         if ((spin & 0x3FF) == 0x3FF) {
             const hipError_t q = hipStreamQuery(s->stream);
-            if (q == hipErrorNotReady) continue;
+            if (q == hipErrorNotReady) {   // still running; give up only on a device that has stopped answering
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::minutes(10)) return fail(2, "bounce loop: no progress on the device for 10 minutes");
+                continue;
+            }
             if (q != hipSuccess) return fail(2, std::string("bounce loop: ") + hipGetErrorString(q));
             const unsigned long long a2 = v[0], b2 = v[1];   // the stream is idle: every store has landed
             if ((uint32_t)(a2 >> 32) == tag && (uint32_t)(b2 >> 32) == tag) { out[0] = (uint32_t)a2; out[1] = (uint32_t)b2; return 0; }
