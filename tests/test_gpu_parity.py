@@ -441,3 +441,25 @@ def test_exact_ties_resolve_like_the_reference(gpu, n_meshes, per_mesh, modes):
         assert np.array_equal(ids, oid), f"mode {mode}: ids"
         assert np.array_equal(bits(tuv), bits(otuv)), f"mode {mode}: t,u,v"
     sc.close()
+
+
+def test_batching_and_repetition_change_nothing(gpu):
+    """How a render call is cut into batches (option batch_paths), and running it twice, must not
+    move a bit: samples are independent and are summed per pixel in ascending sample order."""
+    sc = gpu.Scene(conftest.load_model("cornell"), device=0)
+    eye, look, up, yv = CORNELL_CAM
+    W, H, spp = 128, 72, 12
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    ref = sc.render(cam, W, H, 0, spp, 2, 40, seed=11).copy()
+    again = sc.render(cam, W, H, 0, spp, 2, 40, seed=11)
+    assert np.array_equal(bits(ref), bits(again))
+    for batch in (W * H, 3 * W * H, 5 * W * H + 17):     # 12, 4 and 3 (uneven) batches
+        sc.set_option("batch_paths", batch)
+        img = sc.render(cam, W, H, 0, spp, 2, 40, seed=11)
+        assert np.array_equal(bits(ref), bits(img)), batch
+    # and in two calls that continue one accumulator
+    sc.set_option("batch_paths", 64 << 20)
+    acc = sc.render(cam, W, H, 0, 5, 2, 40, seed=11)
+    acc = sc.render(cam, W, H, 5, spp, 2, 40, seed=11, accum=acc)
+    assert np.array_equal(bits(ref), bits(acc))
+    sc.close()
