@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=128, help="samples per pixel per rank per step (32 = one 64 Mi-path batch at FHD)")
     ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
     ap.add_argument("--tail-paths", type=int, default=-1, help="override the library's tail hand-over threshold (A/B runs)")
+    ap.add_argument("--overlap-below", type=int, default=-1, help="override the library's two-lane overlap threshold (A/B runs; 0 = one lane)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not collect per-kernel HIP-event timings")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -104,6 +105,8 @@ def main():
     scene.set_option("traversal", args.traversal)
     if args.tail_paths >= 0:
         scene.set_option("tail_paths", args.tail_paths)
+    if args.overlap_below >= 0:
+        scene.set_option("overlap_below", args.overlap_below)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     spp = args.spp_per_step
 
@@ -183,7 +186,8 @@ def main():
                                        "library's stream over the timed region); traffic = HBM bytes per launch from the PMC passes "
                                        "in profiles/ (FETCH_SIZE doubled per the gfx950 correction). The kernel is bound by "
                                        "instruction issue (one VALU instruction per 3.2 cycles per SIMD against a measured "
-                                       "sustained 2.84), not by HBM."}
+                                       "sustained 2.84), not by HBM.  Two batches are in flight at batch boundaries, so a launch's "
+                                       "duration includes the time it shares the chip with the other batch's launches."}
             out["kernels"] = kern
             rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
             out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],

@@ -174,6 +174,9 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *   "tail_paths"  a render batch hands its remaining paths to the one-path-per-wave
  *                 tail kernel once at most this many are left (0 = never; small scenes only)
  *   "batch_paths" upper bound on paths in flight per render batch
+ *   "overlap_below" a render call of several batches starts the next batch on a second
+ *                 stream (with queues of its own) once the current batch has fewer rays
+ *                 than this left (default 4 Mi; 0 = one batch at a time, half the memory)
  * Results never depend on these. */
 int orion_hip_scene_set_option(OrionScene* scene, const char* name, int64_t value);
 

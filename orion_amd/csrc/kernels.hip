@@ -49,6 +49,19 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; int kernel; uint64_t items; };
 
+// What one batch of paths in flight owns: a stream, the queues, the bounce counters and their pinned
+// mirror.  Consecutive batches alternate between two lanes so that the head of one batch can run
+// beside the tail of the one before it.
+struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf q[6], hits, rad, counter;
+    // Per-bounce counters travel to the host through a ring: the device slot of bounce d is
+    // d % kRing; the next bounce's extend launch stores it into the pinned mirror
+    // {tag << 32 | vertices, tag << 32 | rays}.
+    unsigned long long* h_count = nullptr;   // pinned and coherent, kRing x 2 words
+    hipEvent_t resolved = nullptr;           // after the lane's newest k_resolve
+};
+
 // Bounce-counter ring: the host launches bounce d while it reads the counters of bounce d - kLag,
 // so the stream always holds queued work and no launch waits on a host round trip.
 constexpr uint32_t kRing = 8, kLag = 2, kClearAhead = 3;
@@ -67,13 +80,11 @@ struct OrionScene {
     int traversal = 0;                // 0 auto, 1 lane, 2 wave, 3 one ray per wave at a time
     uint32_t tail_paths = 1u << 16;   // hand a batch's last paths to k_tail once this few are left
     uint64_t batch_paths = 64u << 20;     // paths in flight per batch (128 B of queues each)
+    uint32_t overlap_below = 4u << 20;    // start the next batch on the other lane once this few rays are left (0: never)
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
-    DevBuf q[6], hits, rad, counter;
-    // Per-bounce counters travel to the host through a ring: the device slot of bounce d is
-    // d % kRing; the next bounce's extend launch stores it into the pinned mirror
-    // {tag << 32 | vertices, tag << 32 | rays}.
-    unsigned long long* h_count = nullptr;   // pinned and coherent, kRing x 2 words
+    Lane lane[2];                     // lane[0].stream == stream
+    hipEvent_t ev_upload = nullptr;   // after the upload of a host accumulator
     uint32_t tag = 0;                 // last tag handed out; a tag is used once per scene
     // profiling
     bool profiling = false;
@@ -93,13 +104,13 @@ struct OrionScene {
 
 namespace {
 
-// Launch on the scene's stream.  With profiling on, the launch carries a start and a stop event
-// bound to the kernel's own dispatch (no extra packets in the stream), so the recorded time is the
-// kernel's execution time and the stream runs as it does unprofiled.
+// Launch on one of the scene's streams.  With profiling on, the launch carries a start and a stop
+// event bound to the kernel's own dispatch (no extra packets in the stream), so the recorded time is
+// the kernel's execution time and the stream runs as it does unprofiled.
 template <typename... KArgs, typename... Args>
-void launch(OrionScene* s, int kernel_id, uint64_t items, void (*kernel)(KArgs...), dim3 grid, dim3 block, Args&&... args) {
+void launch_on(OrionScene* s, hipStream_t stream, int kernel_id, uint64_t items, void (*kernel)(KArgs...), dim3 grid, dim3 block, Args&&... args) {
     if (!s->profiling) {
-        hipLaunchKernelGGL(kernel, grid, block, 0, s->stream, static_cast<KArgs>(args)...);
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, static_cast<KArgs>(args)...);
         return;
     }
     auto take = [&]() {
@@ -109,8 +120,13 @@ void launch(OrionScene* s, int kernel_id, uint64_t items, void (*kernel)(KArgs..
         return e;
     };
     EventPair ev{take(), take(), kernel_id, items};
-    hipExtLaunchKernelGGL(kernel, grid, block, 0, s->stream, ev.a, ev.b, 0, static_cast<KArgs>(args)...);
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev.a, ev.b, 0, static_cast<KArgs>(args)...);
     s->pending.push_back(ev);
+}
+
+template <typename... KArgs, typename... Args>
+void launch(OrionScene* s, int kernel_id, uint64_t items, void (*kernel)(KArgs...), dim3 grid, dim3 block, Args&&... args) {
+    launch_on(s, s->stream, kernel_id, items, kernel, grid, block, std::forward<Args>(args)...);
 }
 
 void drain_profile(OrionScene* s) {
@@ -195,7 +211,7 @@ struct Flattener {
 // Waits until the device has stored both counters of a bounce under `tag` into their pinned slot.
 // The wait is a poll of host memory; it gives up when the stream has drained (or failed) without
 // the tag turning up.
-int await_counters(OrionScene* s, const unsigned long long* slot, uint32_t tag, uint32_t out[2]) {
+int await_counters(hipStream_t stream, const unsigned long long* slot, uint32_t tag, uint32_t out[2]) {
     const volatile unsigned long long* v = slot;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spin = 0;; spin++) {
@@ -203,7 +219,7 @@ int await_counters(OrionScene* s, const unsigned long long* slot, uint32_t tag, 
         if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) { out[0] = (uint32_t)a; out[1] = (uint32_t)b; return 0; }
         for (int k = 0; k < 32; k++) __builtin_ia32_pause();   // poll gently: the device's store has to win the line
         if ((spin & 0x3FF) == 0x3FF) {
-            const hipError_t q = hipStreamQuery(s->stream);
+            const hipError_t q = hipStreamQuery(stream);
             if (q == hipErrorNotReady) {   // still running; give up only on a device that has stopped answering
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::minutes(10)) return fail(2, "bounce loop: no progress on the device for 10 minutes");
                 continue;
@@ -430,8 +446,14 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     s->device = device;
     auto bail = [&](int rc) { orion_hip_scene_destroy(s); return rc; };
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { s->stream = nullptr; return bail(fail(2, "hipStreamCreate failed")); }
-    if (hipHostMalloc((void**)&s->h_count, kRing * 16, hipHostMallocCoherent) != hipSuccess) { s->h_count = nullptr; return bail(fail(2, "hipHostMalloc failed")); }
-    std::memset(s->h_count, 0, kRing * 16);
+    s->lane[0].stream = s->stream;
+    if (hipStreamCreateWithFlags(&s->lane[1].stream, hipStreamNonBlocking) != hipSuccess) { s->lane[1].stream = nullptr; return bail(fail(2, "hipStreamCreate failed")); }
+    for (Lane& L : s->lane) {
+        if (hipHostMalloc((void**)&L.h_count, kRing * 16, hipHostMallocCoherent) != hipSuccess) { L.h_count = nullptr; return bail(fail(2, "hipHostMalloc failed")); }
+        std::memset(L.h_count, 0, kRing * 16);
+        if (hipEventCreateWithFlags(&L.resolved, hipEventDisableTiming) != hipSuccess) { L.resolved = nullptr; return bail(fail(2, "hipEventCreate failed")); }
+    }
+    if (hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming) != hipSuccess) { s->ev_upload = nullptr; return bail(fail(2, "hipEventCreate failed")); }
     SceneView& v = s->view;
     int rc = 0;
     if ((rc = upload(s, nodes, &v.nodes))) return bail(rc);
@@ -455,15 +477,19 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
 int orion_hip_scene_destroy(OrionScene* s) {
     if (!s) return 0;
     DeviceGuard guard(s->device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (Lane& L : s->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
     drain_profile(s);
     for (hipEvent_t e : s->pool) (void)hipEventDestroy(e);
     for (void* p : s->owned) (void)hipFree(p);
     s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release();
-    for (DevBuf& b : s->q) b.release();
-    s->hits.release(); s->rad.release(); s->counter.release();
-    if (s->h_count) (void)hipHostFree(s->h_count);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    for (Lane& L : s->lane) {
+        for (DevBuf& b : L.q) b.release();
+        L.hits.release(); L.rad.release(); L.counter.release();
+        if (L.h_count) (void)hipHostFree(L.h_count);
+        if (L.resolved) (void)hipEventDestroy(L.resolved);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (s->ev_upload) (void)hipEventDestroy(s->ev_upload);
     delete s;
     return 0;
 }
@@ -479,6 +505,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
     if (!std::strcmp(name, "tail_paths")) {
         if (value < 0 || value > (int64_t)1 << 24) return fail(1, "set_option: tail_paths out of range");
         s->tail_paths = (uint32_t)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "overlap_below")) {
+        if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: overlap_below out of range");
+        s->overlap_below = (uint32_t)value;
         return 0;
     }
     if (!std::strcmp(name, "batch_paths")) {
@@ -568,98 +599,145 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         if (int rc = s->s_accum.reserve(img_bytes)) return rc;
         d_accum = static_cast<float4*>(s->s_accum.p);
         HIP_TRY(hipMemcpyAsync(d_accum, accum_any, img_bytes, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->ev_upload, s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->lane[1].stream, s->ev_upload, 0));
     }
-    for (DevBuf& b : s->q) if (int rc = b.reserve(max_paths * 16)) return rc;
-    if (int rc = s->hits.reserve(max_paths * 16)) return rc;
-    if (int rc = s->rad.reserve(max_paths * 16)) return rc;
-    if (int rc = s->counter.reserve(kRing * 16)) return rc;
-    unsigned long long* d_count = static_cast<unsigned long long*>(s->counter.p);
-    Queues qa{static_cast<float4*>(s->q[0].p), static_cast<float4*>(s->q[1].p), static_cast<float4*>(s->q[2].p)};
-    Queues qb{static_cast<float4*>(s->q[3].p), static_cast<float4*>(s->q[4].p), static_cast<float4*>(s->q[5].p)};
-    HitRec* d_hits = static_cast<HitRec*>(s->hits.p);
-    float4* d_rad = static_cast<float4*>(s->rad.p);
     const int mode = s->mode();
     const bool tail_ok = s->view.n_items != 0 && mode != MODE_LANE && s->tail_paths != 0;
     const uint64_t rays_per_vertex = point ? p->n_lights : (uint64_t)p->light_samples * s->view.n_emissive;
+    const uint32_t n_bins = (mode != MODE_LANE) ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
+    const uint64_t n_batches = (p->spp_end - p->spp_begin + per_batch - 1) / per_batch;
+    const bool two_lanes = n_batches > 1 && s->overlap_below != 0;
 
-    for (uint64_t sb = p->spp_begin; sb < p->spp_end; sb += per_batch) {
-        const uint32_t ns = (uint32_t)((p->spp_end - sb < per_batch) ? (p->spp_end - sb) : per_batch);
-        F.spp_begin = (uint32_t)sb; F.n_samples = ns;
-        const uint32_t n0 = (uint32_t)(P * ns);
-        HIP_TRY(hipMemsetAsync(d_count, 0, kRing * 16, s->stream));
-        // qa: rays waiting for their closest hit; qb + d_hits: the vertices that hit, ready to shade.
-        // Counter slot of bounce d (two 64-bit words at d % kRing): [0] vertices k_extend kept,
-        // [1] rays k_shade emitted for bounce d + 1.  The kernels read their counts on the device;
-        // the host only needs an upper bound to size the grids and the zero that ends the loop, and
-        // takes both from the bounce kLag launches back.
-        const uint32_t n_bins = (mode != MODE_LANE) ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
-        uint32_t bound = n0;          // >= the number of rays entering the next bounce to launch
+    // One batch of paths in flight: its lane and the host's view of its bounce loop.
+    // qa: rays waiting for their closest hit; qb + hits: the vertices that hit, ready to shade.
+    // Counter slot of bounce d (two 64-bit words at d % kRing): [0] vertices k_extend kept,
+    // [1] rays k_shade emitted for bounce d + 1.  The kernels read their counts on the device;
+    // the host only needs an upper bound to size the grids and the zero that ends the loop, and
+    // takes both from the bounce kLag launches back.
+    struct Batch {
+        Lane* L = nullptr;
+        FrameParams F;
+        Queues qa, qb;
+        HitRec* hits = nullptr;
+        float4* rad = nullptr;
+        unsigned long long* count = nullptr;
+        uint32_t bound = 0;           // >= the number of rays entering the next bounce to launch
         uint32_t consumed = 0;        // bounces whose counters the host has read
         uint32_t launched = 0;
-        uint64_t rays_in = n0;        // rays that entered bounce `consumed`
+        uint64_t rays_in = 0;         // rays that entered bounce `consumed`
         uint32_t tags[kRing] = {};
-        auto consume = [&]() -> int { // read the counters of bounce `consumed`
-            const uint32_t slot = consumed % kRing;
-            uint32_t h[2];
-            if (int rc = await_counters(s, s->h_count + 2 * slot, tags[slot], h)) return rc;
-            if (s->profiling) {
-                s->stats[ORION_KERNEL_CLOSEST_HIT].items += rays_in;
-                s->stats[ORION_KERNEL_SHADE].items += h[0];
-                s->stats[ORION_KERNEL_SHADOW].launches++;   // light-sample / shadow rays traced inside the shade launch
-                s->stats[ORION_KERNEL_SHADOW].items += (uint64_t)h[0] * rays_per_vertex;
+    };
+    auto begin = [&](Batch& B, uint64_t index) -> int {
+        Lane& L = s->lane[two_lanes ? (index & 1) : 0];
+        for (DevBuf& b : L.q) if (int rc = b.reserve(max_paths * 16)) return rc;
+        if (int rc = L.hits.reserve(max_paths * 16)) return rc;
+        if (int rc = L.rad.reserve(max_paths * 16)) return rc;
+        if (int rc = L.counter.reserve(kRing * 16)) return rc;
+        B = Batch{};
+        B.L = &L;
+        B.F = F;
+        const uint64_t sb = p->spp_begin + index * per_batch;
+        const uint32_t ns = (uint32_t)((p->spp_end - sb < per_batch) ? (p->spp_end - sb) : per_batch);
+        B.F.spp_begin = (uint32_t)sb; B.F.n_samples = ns;
+        B.qa = Queues{static_cast<float4*>(L.q[0].p), static_cast<float4*>(L.q[1].p), static_cast<float4*>(L.q[2].p)};
+        B.qb = Queues{static_cast<float4*>(L.q[3].p), static_cast<float4*>(L.q[4].p), static_cast<float4*>(L.q[5].p)};
+        B.hits = static_cast<HitRec*>(L.hits.p);
+        B.rad = static_cast<float4*>(L.rad.p);
+        B.count = static_cast<unsigned long long*>(L.counter.p);
+        B.bound = (uint32_t)(P * ns);
+        B.rays_in = B.bound;
+        HIP_TRY(hipMemsetAsync(B.count, 0, kRing * 16, L.stream));
+        return 0;
+    };
+    // Launches bounce `depth` of a batch: closest hits, then shading.
+    auto bounce = [&](Batch& B, uint32_t depth) -> int {
+        const uint32_t slot = depth % kRing, prev_slot = (depth + kRing - 1) % kRing;
+        unsigned long long* cnt = B.count + 2 * slot;
+        const unsigned long long* prev = depth ? B.count + 2 * prev_slot : nullptr;
+        unsigned long long* clear = B.count + 2 * ((depth + kClearAhead) % kRing);
+        B.tags[slot] = ++s->tag;     // bounce `depth` is published under this tag by the next extend launch
+        const bool wide = B.bound >= kNarrowBelow;
+        const uint32_t tile = wide ? kTileWide : kBlock;
+        auto extend = [&](auto kernel) {
+            launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((B.bound + tile - 1) / tile), dim3(kBlock), s->view, B.F, B.rad, B.qa,
+                      prev, B.bound, B.qb, B.hits, cnt, clear, B.L->h_count + 2 * prev_slot, B.tags[prev_slot], n_bins);
+        };
+        with_mode(mode, [&](auto M) {
+            constexpr int MODE = decltype(M)::value;
+            if (depth == 0) {   // primary rays are generated inside the launch
+                if (wide) extend(k_extend<MODE, kRaysWide, true>); else extend(k_extend<MODE, 1, true>);
+            } else {
+                if (wide) extend(k_extend<MODE, kRaysWide, false>); else extend(k_extend<MODE, 1, false>);
             }
-            rays_in = h[1];
-            consumed++;
+            auto shade = point ? k_shade<MODE, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf : k_shade<MODE, false>);
+            launch_on(s, B.L->stream, ORION_KERNEL_SHADE, 0, shade, dim3(grid_for(B.bound)), dim3(kBlock), s->view, B.F, depth, B.qb, cnt, B.hits, B.qa, cnt + 1, B.rad);
+        });
+        HIP_TRY(hipGetLastError());
+        B.launched = depth + 1;
+        return 0;
+    };
+    auto consume = [&](Batch& B) -> int { // read the counters of bounce `consumed`
+        const uint32_t slot = B.consumed % kRing;
+        uint32_t h[2];
+        if (int rc = await_counters(B.L->stream, B.L->h_count + 2 * slot, B.tags[slot], h)) return rc;
+        if (s->profiling) {
+            s->stats[ORION_KERNEL_CLOSEST_HIT].items += B.rays_in;
+            s->stats[ORION_KERNEL_SHADE].items += h[0];
+            s->stats[ORION_KERNEL_SHADOW].launches++;   // light-sample / shadow rays traced inside the shade launch
+            s->stats[ORION_KERNEL_SHADOW].items += (uint64_t)h[0] * rays_per_vertex;
+        }
+        B.rays_in = h[1];
+        B.consumed++;
+        return 0;
+    };
+
+    Batch cur, next;
+    bool next_begun = false;
+    Lane* last_resolve = nullptr;
+    for (uint64_t index = 0; index < n_batches; index++) {
+        if (next_begun) { cur = next; next_begun = false; }
+        else if (int rc = begin(cur, index)) return rc;
+        // Once this batch is down to its thin tail (launches that leave most of the chip idle), the
+        // next batch's first kLag bounces -- which need no counts from the host -- go to the other lane.
+        auto start_next = [&]() -> int {
+            if (next_begun || !two_lanes || index + 1 >= n_batches) return 0;
+            if (int rc = begin(next, index + 1)) return rc;
+            for (uint32_t d = 0; d < kLag && d <= p->max_depth; d++) if (int rc = bounce(next, d)) return rc;
+            next_begun = true;
             return 0;
         };
-        for (uint32_t depth = 0; depth <= p->max_depth; depth++) {
-            const uint32_t slot = depth % kRing, prev_slot = (depth + kRing - 1) % kRing;
-            unsigned long long* cnt = d_count + 2 * slot;
-            const unsigned long long* prev = depth ? d_count + 2 * prev_slot : nullptr;
-            unsigned long long* clear = d_count + 2 * ((depth + kClearAhead) % kRing);
-            tags[slot] = ++s->tag;     // bounce `depth` is published under this tag by the next extend launch
-            const bool wide = bound >= kNarrowBelow;
-            const uint32_t tile = wide ? kTileWide : kBlock;
-            auto extend = [&](auto kernel) {
-                launch(s, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((bound + tile - 1) / tile), dim3(kBlock), s->view, F, d_rad, qa,
-                       prev, bound, qb, d_hits, cnt, clear, s->h_count + 2 * prev_slot, tags[prev_slot], n_bins);
-            };
-            with_mode(mode, [&](auto M) {
-                constexpr int MODE = decltype(M)::value;
-                if (depth == 0) {   // primary rays are generated inside the launch
-                    if (wide) extend(k_extend<MODE, kRaysWide, true>); else extend(k_extend<MODE, 1, true>);
-                } else {
-                    if (wide) extend(k_extend<MODE, kRaysWide, false>); else extend(k_extend<MODE, 1, false>);
-                }
-                auto shade = point ? k_shade<MODE, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf : k_shade<MODE, false>);
-                launch(s, ORION_KERNEL_SHADE, 0, shade, dim3(grid_for(bound)), dim3(kBlock), s->view, F, depth, qb, cnt, d_hits, qa, cnt + 1, d_rad);
-            });
-            HIP_TRY(hipGetLastError());
-            launched = depth + 1;
+        for (uint32_t depth = cur.launched; depth <= p->max_depth; depth++) {
+            if (int rc = bounce(cur, depth)) return rc;
             if (depth >= kLag) {
-                if (int rc = consume()) return rc;
-                if (rays_in == 0) break;          // bounce `consumed` has no rays; the ones launched past it find none either
-                bound = (uint32_t)rays_in;
+                if (int rc = consume(cur)) return rc;
+                if (cur.rays_in == 0) break;          // bounce `consumed` has no rays; the ones launched past it find none either
+                cur.bound = (uint32_t)cur.rays_in;
+                if (cur.bound < s->overlap_below) if (int rc = start_next()) return rc;
                 // Few paths left: one launch takes each of them to its end (one wave per path).  The
                 // rays it starts from are the ones the last shade launch emitted, at most `bound`.
-                if (tail_ok && bound <= s->tail_paths && launched <= p->max_depth) {
-                    launch(s, ORION_KERNEL_TAIL, bound, point ? k_tail<true> : k_tail<false>, dim3((bound + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
-                           s->view, F, launched, qa, d_count + 2 * ((launched - 1) % kRing), d_rad);
+                if (tail_ok && cur.bound <= s->tail_paths && cur.launched <= p->max_depth) {
+                    launch_on(s, cur.L->stream, ORION_KERNEL_TAIL, cur.bound, point ? k_tail<true> : k_tail<false>, dim3((cur.bound + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
+                              s->view, cur.F, cur.launched, cur.qa, cur.count + 2 * ((cur.launched - 1) % kRing), cur.rad);
                     HIP_TRY(hipGetLastError());
                     break;
                 }
             }
         }
         if (s->profiling) {   // the statistics want every bounce; the last one has no extend launch after it
-            const uint32_t last = (launched - 1) % kRing;
-            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s->stream, d_count + 2 * last, s->h_count + 2 * last, tags[last]);
-            while (consumed < launched) if (int rc = consume()) return rc;
+            const uint32_t last = (cur.launched - 1) % kRing;
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, cur.L->stream, cur.count + 2 * last, cur.L->h_count + 2 * last, cur.tags[last]);
+            while (cur.consumed < cur.launched) if (int rc = consume(cur)) return rc;
         }
-        launch(s, ORION_KERNEL_RESOLVE, P, k_resolve, dim3(grid_for(P)), dim3(kBlock), F, d_rad, d_accum);
+        // The accumulator takes the batches' sums in ascending sample order, whichever lane they ran on.
+        if (last_resolve && last_resolve != cur.L) HIP_TRY(hipStreamWaitEvent(cur.L->stream, last_resolve->resolved, 0));
+        launch_on(s, cur.L->stream, ORION_KERNEL_RESOLVE, P, k_resolve, dim3(grid_for(P)), dim3(kBlock), cur.F, cur.rad, d_accum);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(cur.L->resolved, cur.L->stream));
+        last_resolve = cur.L;
     }
-    if (!accum_dev) HIP_TRY(hipMemcpyAsync(accum_any, d_accum, img_bytes, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (!accum_dev) HIP_TRY(hipMemcpyAsync(accum_any, d_accum, img_bytes, hipMemcpyDeviceToHost, last_resolve->stream));
+    for (Lane& L : s->lane) HIP_TRY(hipStreamSynchronize(L.stream));
     return 0;
 }
 

@@ -463,3 +463,37 @@ def test_batching_and_repetition_change_nothing(gpu):
     acc = sc.render(cam, W, H, 5, spp, 2, 40, seed=11, accum=acc)
     assert np.array_equal(bits(ref), bits(acc))
     sc.close()
+
+
+@pytest.mark.gpu
+def test_two_lanes_change_nothing(gpu):
+    """Consecutive batches alternate between two streams and overlap (option overlap_below: the next
+    batch starts once the current one has that few rays left).  Whether and when they overlap must
+    not move a bit, for a host accumulator and for a device one."""
+    import torch
+    sc = gpu.Scene(conftest.load_model("cornell"), device=0)
+    eye, look, up, yv = CORNELL_CAM
+    W, H, spp = 640, 360, 20
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    sc.set_option("overlap_below", 0)                      # one lane, one batch
+    ref = sc.render(cam, W, H, 0, spp, 2, 60, seed=5).copy()
+    sc.set_option("batch_paths", 4 * W * H)                # five batches of 0.9 Mi paths
+    for below in (0, 1, 100_000, 600_000, 1 << 30):
+        sc.set_option("overlap_below", below)
+        img = sc.render(cam, W, H, 0, spp, 2, 60, seed=5)
+        assert np.array_equal(bits(ref), bits(img)), below
+        dev = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        sc.render(cam, W, H, 0, spp, 2, 60, seed=5, accum=dev)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(ref), bits(dev.cpu().numpy())), below
+    # uneven last batch, and point lights (any-hit shadow rays) through the same loop
+    sc.set_option("batch_paths", 3 * W * H)
+    img = sc.render(cam, W, H, 0, spp, 2, 60, seed=5)
+    assert np.array_equal(bits(ref), bits(img))
+    lights = np.array([[0, 1.5, 1.0, 100 / 255, 100 / 255, 100 / 255, 32]], np.float32)
+    sc.set_option("overlap_below", 0); sc.set_option("batch_paths", 64 << 20)
+    pref = sc.render(cam, W, H, 0, 8, 1, 6, seed=5, lights=lights).copy()
+    sc.set_option("overlap_below", 1 << 30); sc.set_option("batch_paths", 2 * W * H)
+    pimg = sc.render(cam, W, H, 0, 8, 1, 6, seed=5, lights=lights)
+    assert np.array_equal(bits(pref), bits(pimg))
+    sc.close()
