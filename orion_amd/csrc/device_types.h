@@ -95,6 +95,9 @@ struct SceneView {
     uint32_t n_emissive;
     const WaveItem* items;        // one-ray-per-wave table, n_items entries (0: the scene is too large for it)
     uint32_t n_items;
+    // Rays whose direction components are all below this in magnitude cannot produce a triangle
+    // determinant of 2^126 or more in this scene (0 if the scene has non-finite edges).
+    float dir_bound;
 };
 
 // Closest-hit record kept in the queues: 16 bytes.  gtri == kInvalid is a miss.

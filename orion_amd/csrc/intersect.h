@@ -13,7 +13,9 @@
 //               only ever changes the sign of a zero result; it is applied when a
 //               hit is accepted (canon()) and skipped in the rejection tests,
 //               whose comparisons cannot see the sign of zero;
-//   divisions:  IEEE, correctly rounded (hipcc's default for FP32 '/').
+//   divisions:  IEEE, correctly rounded (hipcc's default for FP32 '/').  The two reciprocals of the
+//               walk, 1/dir and 1/det, take a 3-instruction form (recip_quick) for rays whose
+//               divisors are provably in the range where it returns the division's bits.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -94,13 +96,39 @@ __device__ __forceinline__ bool slab_safe(V3 o, V3 inv) {
     return o_ok && i_ok;
 }
 
+__device__ __forceinline__ V3 ray_inverse(V3 d) { return mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+
+// 1 / x as the hardware's reciprocal estimate and one Newton step.  For every float with
+// 2^-126 <= |x| < 2^126 this returns the bits of the correctly rounded division (checked for each
+// of them, tools/micro/rcp_exact.hip) in 3 instructions instead of 11; outside that range
+// (zero, denormals, the top two binades, infinities) it does not, and the callers divide.
+__device__ __forceinline__ float recip_quick(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ V3 ray_inverse_quick(V3 d) { return mk(recip_quick(d.x), recip_quick(d.y), recip_quick(d.z)); }
+
+// Which rays may take the quick reciprocals.  `small`: every |component| of the direction is
+// below the scene's bound (SceneView::dir_bound <= 2^126), chosen at upload so that no triangle's
+// determinant can then reach 2^126 -- with the |det| >= 1e-6 test of the triangle routine that
+// puts every divisor in recip_quick's range.  `normal`: also no component below 2^-126, so the
+// ray's own reciprocals are in range.  NaN components fail both.
+__device__ __forceinline__ void dir_class(V3 d, float bound, bool& small, bool& normal) {
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    small = ax < bound && ay < bound && az < bound;
+    const float tiny = 1.17549435e-38f;   // 2^-126
+    normal = small && ax >= tiny && ay >= tiny && az >= tiny;
+}
+
 // Triangle::intersect (orion/geometry.hpp:80-136).  Updates h on acceptance.
+// QUICK: the ray is one for which recip_quick() returns the division's bits (see dir_class below).
+template <bool QUICK>
 __device__ __forceinline__ bool tri_hit(V3 v0, V3 e1, V3 e2, uint32_t gtri, V3 o, V3 d, HitRec& h) {
     const float eps = 0.000001f;
     V3 pvec = cross(d, e2);
     float det = dot_raw(e1, pvec);
     if (det > -eps && det < eps) return false;
-    float inv_det = 1.0f / det;
+    float inv_det = QUICK ? recip_quick(det) : 1.0f / det;
     V3 tvec = o - v0;
     float du = dot_raw(tvec, pvec);
     float u = du * inv_det;
@@ -119,8 +147,6 @@ __device__ __forceinline__ bool tri_hit(V3 v0, V3 e1, V3 e2, uint32_t gtri, V3 o
     return true;
 }
 
-__device__ __forceinline__ V3 ray_inverse(V3 d) { return mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
-
 __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------------------
@@ -135,10 +161,8 @@ __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]);
 // branch, the box), which turns one memory round trip per node into two dependent ones.
 __device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
-template <bool ANY>
-__device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, HitRec& h) {
-    const V3 inv = ray_inverse(d);
-    const bool fast = __all(slab_safe(o, inv));   // wave-uniform choice of the slab arithmetic
+template <bool ANY, bool QUICK>
+__device__ __forceinline__ void traverse_lane_walk(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, HitRec& h) {
     uint32_t node = 0;
     const uint32_t n_nodes = S.n_nodes;
     while (node < n_nodes) {
@@ -152,7 +176,7 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
                 const float4* tp = reinterpret_cast<const float4*>(S.tris + (a + s));
                 float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
                 pin(T0); pin(T1); pin(T2);
-                bool acc = tri_hit(mk(T0.x, T0.y, T0.z), mk(T1.x, T1.y, T1.z), mk(T2.x, T2.y, T2.z), __float_as_uint(T0.w), o, d, h);
+                bool acc = tri_hit<QUICK>(mk(T0.x, T0.y, T0.z), mk(T1.x, T1.y, T1.z), mk(T2.x, T2.y, T2.z), __float_as_uint(T0.w), o, d, h);
                 if (ANY && acc) return;
             }
             node++;
@@ -161,6 +185,17 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
             node = in ? node + 1 : a;
         }
     }
+}
+
+template <bool ANY>
+__device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, HitRec& h) {
+    bool d_small, d_normal;
+    dir_class(d, S.dir_bound, d_small, d_normal);
+    const bool quick_det = __all(d_small), quick_inv = __all(d_normal);   // wave-uniform choices of the arithmetic
+    const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
+    const bool fast = __all(slab_safe(o, inv));
+    if (quick_det) traverse_lane_walk<ANY, true>(S, o, d, inv, fast, h);
+    else traverse_lane_walk<ANY, false>(S, o, d, inv, fast, h);
 }
 
 // ---------------------------------------------------------------------------
@@ -172,18 +207,35 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
 // paths, which for scenes of a few dozen nodes is close to every lane's own path.
 // Must be entered by all lanes that want a result; `active` = false lanes idle.
 // ---------------------------------------------------------------------------
+template <bool QUICK_DIV>
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast);
+template <bool ANY, bool QUICK>
+__device__ __forceinline__ void traverse_wave_loop(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, uint32_t next, HitRec& h);
 
 template <bool ANY>
 __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
-    const V3 inv = ray_inverse(d);
+    bool d_small, d_normal;
+    dir_class(d, S.dir_bound, d_small, d_normal);
+    const bool quick_det = __all(!active || d_small), quick_inv = __all(!active || d_normal);   // wave-uniform
+    const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
     const bool fast = __all(!active || slab_safe(o, inv));   // wave-uniform choice of the slab arithmetic
     uint32_t next = active ? 0u : kInvalid;
     const uint32_t n_nodes = S.n_nodes;
     if (!ANY) {   // the closest-hit walk is hand-scheduled; the loop below is the any-hit walk
-        if (n_nodes) traverse_wave_closest_asm(S, o, d, inv, h, next, __builtin_amdgcn_readfirstlane(fast ? 1u : 0u));
+        const uint32_t ufast = __builtin_amdgcn_readfirstlane(fast ? 1u : 0u);
+        if (n_nodes) {
+            if (quick_det) traverse_wave_closest_asm<true>(S, o, d, inv, h, next, ufast);
+            else traverse_wave_closest_asm<false>(S, o, d, inv, h, next, ufast);
+        }
         return;
     }
+    if (quick_det) traverse_wave_loop<ANY, true>(S, o, d, inv, fast, next, h);
+    else traverse_wave_loop<ANY, false>(S, o, d, inv, fast, next, h);
+}
+
+template <bool ANY, bool QUICK>
+__device__ __forceinline__ void traverse_wave_loop(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, uint32_t next, HitRec& h) {
+    const uint32_t n_nodes = S.n_nodes;
     for (uint32_t node = 0; node < n_nodes; node++) {
         const uint32_t un = __builtin_amdgcn_readfirstlane(node);   // the walk is wave-uniform: keep it in SGPRs
         const bool mine = (next == un);
@@ -202,7 +254,7 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
                 // The lanes that are not at this node sit the test out (execution mask), so its
                 // early exits fire as soon as the few lanes that are here have failed.
                 if (mine && !(ANY && done)) {
-                    bool acc = tri_hit(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.e1[0], T.e1[1], T.e1[2]),
+                    bool acc = tri_hit<QUICK>(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.e1[0], T.e1[1], T.e1[2]),
                                        mk(T.e2[0], T.e2[1], T.e2[2]), T.gtri, o, d, h);
                     if (ANY && acc) done = true;
                 }
@@ -240,7 +292,10 @@ __device__ __forceinline__ void traverse_one(const SceneView& S, V3 o, V3 d, Hit
     const float4 A = ip[0], B = ip[1], C = ip[2], D = ip[3];
     const uint32_t kind = __float_as_uint(B.w);
     const uint64_t anc = (uint64_t)__float_as_uint(D.x) | ((uint64_t)__float_as_uint(D.y) << 32);
-    const V3 inv = ray_inverse(d);
+    bool d_small, d_normal;
+    dir_class(d, S.dir_bound, d_small, d_normal);
+    d_small = __all(d_small); d_normal = __all(d_normal);   // every lane holds the same ray: branches, not selects
+    const V3 inv = d_normal ? ray_inverse_quick(d) : ray_inverse(d);
     // boxes
     const bool in = slab_safe(o, inv) ? slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv) : slab_hit(A.x, A.y, A.z, B.x, B.y, B.z, o, inv);
     const uint64_t box_hit = __ballot(kind == 1u && in);
@@ -250,7 +305,7 @@ __device__ __forceinline__ void traverse_one(const SceneView& S, V3 o, V3 d, Hit
     const V3 pvec = cross(d, e2);
     const float det = dot_raw(e1, pvec);
     bool ok = !(det > -eps && det < eps);
-    const float inv_det = 1.0f / det;
+    const float inv_det = d_small ? recip_quick(det) : 1.0f / det;   // only read where ok
     const V3 tvec = o - v0;
     const float du = dot_raw(tvec, pvec);
     const float u = du * inv_det;
@@ -310,7 +365,8 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 // ---------------------------------------------------------------------------
 // The closest-hit wave walk, hand-scheduled.  The algorithm of traverse_wave
 // and the FP32 operations of slab_hit / slab_hit_fast and tri_hit in the same
-// order (the division is the compiler's own correctly rounded sequence), but
+// order (the division is the compiler's own correctly rounded sequence, or recip_quick where
+// QUICK_DIV says the wave's rays allow it), but
 // with what the compiler will not do for this loop: one scalar pointer that
 // steps through the node array, one 48-byte scalar fetch per triangle, the
 // execution mask narrowed stage by stage with a single restore per triangle,
@@ -321,6 +377,202 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 // walk is only chosen for scenes of a few dozen nodes).  SGPRs s52-s63 hold the
 // node or triangle being processed.
 // ---------------------------------------------------------------------------
+#define ORION_WALK_BEFORE_DIV \
+        "s_mov_b64 %[EX], exec\n"                                                                           \
+        "s_mov_b32 %[noff], 0\n"  /* byte offset of the node, steps by 32 */                                \
+        "s_mov_b32 %[node], 0\n"                                                                            \
+        "s_mov_b32 %[eps], 0x358637bd\n"  /* 1e-6f */                                                       \
+        "L_node%=:\n"                                                                                       \
+        "v_cmp_eq_u32_e64 %[MI], %[node], %[nx]\n"                                                          \
+        "s_cmp_eq_u64 %[MI], 0\n"                                                                           \
+        "s_cbranch_scc1 L_next%=\n"                                                                         \
+        "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n"  /* lo.xyz a | hi.xyz b */                           \
+        "s_add_u32 %[node1], %[node], 1\n"                                                                  \
+        "s_waitcnt lgkmcnt(0)\n"                                                                            \
+        "s_bitcmp1_b32 s59, 31\n"                                                                           \
+        "s_cbranch_scc1 L_leaf%=\n"                                                                         \
+        /* ---- inner node: slab test, next = in ? node + 1 : skip */                                       \
+        "v_sub_f32 %[aa], s52, %[ox]\n"                                                                     \
+        "v_sub_f32 %[bb], s56, %[ox]\n"                                                                     \
+        "v_sub_f32 %[cc], s53, %[oy]\n"                                                                     \
+        "v_sub_f32 %[uu], s57, %[oy]\n"                                                                     \
+        "v_sub_f32 %[du], s54, %[oz]\n"                                                                     \
+        "v_sub_f32 %[dv], s58, %[oz]\n"                                                                     \
+        "v_mul_f32 %[aa], %[aa], %[ix]\n"                                                                   \
+        "v_mul_f32 %[bb], %[bb], %[ix]\n"                                                                   \
+        "v_mul_f32 %[cc], %[cc], %[iy]\n"                                                                   \
+        "v_mul_f32 %[uu], %[uu], %[iy]\n"                                                                   \
+        "v_mul_f32 %[du], %[du], %[iz]\n"                                                                   \
+        "v_mul_f32 %[dv], %[dv], %[iz]\n"                                                                   \
+        "s_cmp_eq_u32 %[fast], 0\n"                                                                         \
+        "s_cbranch_scc1 L_slab_exact%=\n"                                                                   \
+        "v_min_f32 %[tx], %[aa], %[bb]\n"                                                                   \
+        "v_min_f32 %[ty], %[cc], %[uu]\n"                                                                   \
+        "v_min_f32 %[tz], %[du], %[dv]\n"                                                                   \
+        "v_max_f32 %[aa], %[aa], %[bb]\n"                                                                   \
+        "v_max_f32 %[cc], %[cc], %[uu]\n"                                                                   \
+        "v_max_f32 %[du], %[du], %[dv]\n"                                                                   \
+        "v_max3_f32 %[tx], %[tx], %[ty], %[tz]\n"  /* tmin */                                               \
+        "v_min3_f32 %[aa], %[aa], %[cc], %[du]\n"  /* tmax */                                               \
+        "s_branch L_slab_done%=\n"                                                                          \
+        /* the reference's select order, for waves with a ray whose products can be NaN: */                 \
+        /* lx = (t1<t2)?t1:t2, hx = (t1>t2)?t1:t2, tmin = (lx<m)?m:lx with m = (ly<lz)?lz:ly, */            \
+        /* tmax = (m2<hx)?m2:hx with m2 = (hz<hy)?hz:hy  (orion/AABB.hpp:79-99, orion/math.hpp:336-365) */  \
+        "L_slab_exact%=:\n"                                                                                 \
+        "v_cmp_lt_f32 vcc, %[aa], %[bb]\n s_nop 1\n v_cndmask_b32 %[tx], %[bb], %[aa], vcc\n"               \
+        "v_cmp_lt_f32 vcc, %[cc], %[uu]\n s_nop 1\n v_cndmask_b32 %[ty], %[uu], %[cc], vcc\n"               \
+        "v_cmp_lt_f32 vcc, %[du], %[dv]\n s_nop 1\n v_cndmask_b32 %[tz], %[dv], %[du], vcc\n"               \
+        "v_cmp_gt_f32 vcc, %[aa], %[bb]\n s_nop 1\n v_cndmask_b32 %[aa], %[bb], %[aa], vcc\n"               \
+        "v_cmp_gt_f32 vcc, %[cc], %[uu]\n s_nop 1\n v_cndmask_b32 %[cc], %[uu], %[cc], vcc\n"               \
+        "v_cmp_gt_f32 vcc, %[du], %[dv]\n s_nop 1\n v_cndmask_b32 %[du], %[dv], %[du], vcc\n"               \
+        "v_cmp_lt_f32 vcc, %[ty], %[tz]\n s_nop 1\n v_cndmask_b32 %[ty], %[ty], %[tz], vcc\n"               \
+        "v_cmp_lt_f32 vcc, %[tx], %[ty]\n s_nop 1\n v_cndmask_b32 %[tx], %[tx], %[ty], vcc\n"               \
+        "v_cmp_lt_f32 vcc, %[du], %[cc]\n s_nop 1\n v_cndmask_b32 %[cc], %[cc], %[du], vcc\n"               \
+        "v_cmp_lt_f32 vcc, %[cc], %[aa]\n s_nop 1\n v_cndmask_b32 %[aa], %[aa], %[cc], vcc\n"               \
+        "L_slab_done%=:\n"                                                                                  \
+        "v_cmp_gt_f32 vcc, %[aa], %[tx]\n"                                                                  \
+        "v_cmp_lt_f32_e64 %[PM], 0, %[aa]\n"                                                                \
+        "v_mov_b32 %[bb], %[node1]\n"                                                                       \
+        "v_mov_b32 %[cc], s55\n"                                                                            \
+        "s_and_b64 vcc, vcc, %[PM]\n"                                                                       \
+        "v_cndmask_b32_e32 %[bb], %[cc], %[bb], vcc\n"                                                      \
+        "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"                                                    \
+        "s_branch L_next%=\n"                                                                               \
+        /* ---- leaf: its triangles, for the lanes that are here */                                         \
+        "L_leaf%=:\n"                                                                                       \
+        "s_and_b32 %[cnt], s59, 0x7fffffff\n"  /* triangle count */                                         \
+        "s_cbranch_scc0 L_leaf_done%=\n"                                                                    \
+        "s_mul_i32 %[toff], s55, 48\n"  /* byte offset of the leaf's first triangle */                      \
+        "s_and_b64 exec, %[EX], %[MI]\n"                                                                    \
+        "L_tri%=:\n"                                                                                        \
+        "s_load_dwordx4 s[52:55], %[tris], %[toff]\n"  /* v0.xyz gtri */                                    \
+        "s_load_dwordx4 s[56:59], %[tris], %[toff] offset:0x10\n"  /* e1.xyz */                             \
+        "s_load_dwordx4 s[60:63], %[tris], %[toff] offset:0x20\n"  /* e2.xyz */                             \
+        "s_add_u32 %[toff], %[toff], 48\n"                                                                  \
+        "s_waitcnt lgkmcnt(0)\n"                                                                            \
+        /* pvec = cross(d, e2) */                                                                           \
+        "v_mul_f32 %[px], s62, %[dy]\n"                                                                     \
+        "v_mul_f32 %[py], s60, %[dz]\n"                                                                     \
+        "v_mul_f32 %[pz], s61, %[dx]\n"                                                                     \
+        "v_fma_f32 %[px], -%[dz], s61, %[px]\n"                                                             \
+        "v_fma_f32 %[py], -%[dx], s62, %[py]\n"                                                             \
+        "v_fma_f32 %[pz], -%[dy], s60, %[pz]\n"                                                             \
+        /* det = dot(e1, pvec) */                                                                           \
+        "v_mul_f32 %[aa], s56, %[px]\n"                                                                     \
+        "v_mul_f32 %[bb], s57, %[py]\n"                                                                     \
+        "v_mul_f32 %[cc], s58, %[pz]\n"                                                                     \
+        "v_add_f32 %[aa], %[aa], %[bb]\n"                                                                   \
+        "v_add_f32 %[det], %[aa], %[cc]\n"                                                                  \
+        "v_cmp_nlt_f32_e64 %[PM], |%[det]|, %[eps]\n"                                                       \
+        "s_and_b64 exec, exec, %[PM]\n"                                                                     \
+        "s_cbranch_scc0 L_tri_next%=\n"                                                                    
+#define ORION_WALK_DIV_EXACT \
+        /* inv_det = 1 / det, correctly rounded (q0 = aa, r = bb, q1 = cc, e = tx, m = dt) */  \
+        "v_div_scale_f32 %[aa], %[PM], %[det], %[det], 1.0\n"                                  \
+        "v_rcp_f32 %[bb], %[aa]\n"                                                             \
+        "v_div_scale_f32 %[cc], vcc, 1.0, %[det], 1.0\n"                                       \
+        "v_fma_f32 %[tx], -%[aa], %[bb], 1.0\n"                                                \
+        "v_fmac_f32 %[bb], %[tx], %[bb]\n"                                                     \
+        "v_mul_f32 %[dt], %[cc], %[bb]\n"                                                      \
+        "v_fma_f32 %[tx], -%[aa], %[dt], %[cc]\n"                                              \
+        "v_fmac_f32 %[dt], %[tx], %[bb]\n"                                                     \
+        "v_fma_f32 %[aa], -%[aa], %[dt], %[cc]\n"                                              \
+        "v_div_fmas_f32 %[aa], %[aa], %[bb], %[dt]\n"                                          \
+        "v_div_fixup_f32 %[idet], %[aa], %[det], 1.0\n"                                       \
+        /* tvec = o - v0 */ \
+        "v_subrev_f32 %[tx], s52, %[ox]\n"                                               \
+        "v_subrev_f32 %[ty], s53, %[oy]\n"                                               \
+        "v_subrev_f32 %[tz], s54, %[oz]\n"
+#define ORION_WALK_DIV_QUICK \
+        /* inv_det = 1 / det as reciprocal estimate + one Newton step: the bits of the division for */  \
+        /* 2^-126 <= |det| < 2^126 (every such float checked, tools/micro/rcp_exact.hip) */             \
+        "v_rcp_f32 %[bb], %[det]\n" \
+        /* tvec = o - v0 (also the wait state a reciprocal needs before its result is read) */ \
+        "v_subrev_f32 %[tx], s52, %[ox]\n"                                               \
+        "v_subrev_f32 %[ty], s53, %[oy]\n"                                               \
+        "v_subrev_f32 %[tz], s54, %[oz]\n"                                               \
+        "v_fma_f32 %[aa], -%[det], %[bb], 1.0\n" \
+        "v_fma_f32 %[idet], %[aa], %[bb], %[bb]\n"
+#define ORION_WALK_AFTER_DIV \
+        /* u = dot(tvec, pvec) * inv_det */ \
+        "v_mul_f32 %[aa], %[tx], %[px]\n"                                                \
+        "v_mul_f32 %[bb], %[ty], %[py]\n"                                                \
+        "v_mul_f32 %[cc], %[tz], %[pz]\n"                                                \
+        "v_add_f32 %[aa], %[aa], %[bb]\n"                                                \
+        "v_add_f32 %[du], %[aa], %[cc]\n"                                                \
+        "v_mul_f32 %[uu], %[du], %[idet]\n"                                              \
+        "v_cmp_ngt_f32 vcc, 0, %[uu]\n"                                                  \
+        "v_cmp_nlt_f32_e64 %[PM], 1.0, %[uu]\n"                                          \
+        "s_and_b64 %[PM], vcc, %[PM]\n"                                                  \
+        "s_and_b64 exec, exec, %[PM]\n"                                                  \
+        "s_cbranch_scc0 L_tri_next%=\n"                                                  \
+        /* qvec = cross(tvec, e1) (in pvec's registers), v = dot(d, qvec) * inv_det */   \
+        "v_mul_f32 %[px], s58, %[ty]\n"                                                  \
+        "v_mul_f32 %[py], s56, %[tz]\n"                                                  \
+        "v_mul_f32 %[pz], s57, %[tx]\n"                                                  \
+        "v_fma_f32 %[px], -%[tz], s57, %[px]\n"                                          \
+        "v_fma_f32 %[py], -%[tx], s58, %[py]\n"                                          \
+        "v_fma_f32 %[pz], -%[ty], s56, %[pz]\n"                                          \
+        "v_mul_f32 %[aa], %[dx], %[px]\n"                                                \
+        "v_mul_f32 %[bb], %[dy], %[py]\n"                                                \
+        "v_mul_f32 %[cc], %[dz], %[pz]\n"                                                \
+        "v_add_f32 %[aa], %[aa], %[bb]\n"                                                \
+        "v_add_f32 %[dv], %[aa], %[cc]\n"                                                \
+        "v_mul_f32 %[aa], %[dv], %[idet]\n"                                              \
+        "v_cmp_ngt_f32 vcc, 0, %[aa]\n"                                                  \
+        "v_add_f32 %[bb], %[uu], %[aa]\n"                                                \
+        "v_cmp_nlt_f32_e64 %[PM], 1.0, %[bb]\n"                                          \
+        "s_and_b64 %[PM], vcc, %[PM]\n"                                                  \
+        "s_and_b64 exec, exec, %[PM]\n"                                                  \
+        "s_cbranch_scc0 L_tri_next%=\n"                                                  \
+        /* t = dot(e2, qvec) * inv_det */                                                \
+        "v_mul_f32 %[aa], s60, %[px]\n"                                                  \
+        "v_mul_f32 %[bb], s61, %[py]\n"                                                  \
+        "v_mul_f32 %[cc], s62, %[pz]\n"                                                  \
+        "v_add_f32 %[aa], %[aa], %[bb]\n"                                                \
+        "v_add_f32 %[dt], %[aa], %[cc]\n"                                                \
+        "v_mul_f32 %[bb], %[dt], %[idet]\n"                                              \
+        "v_cmp_ngt_f32 vcc, %[bb], %[ht]\n"                                              \
+        "v_cmp_ngt_f32_e64 %[PM], 0, %[bb]\n"                                            \
+        "s_and_b64 %[PM], vcc, %[PM]\n"                                                  \
+        "s_and_b64 exec, exec, %[PM]\n"                                                  \
+        "s_cbranch_scc0 L_tri_next%=\n"                                                  \
+        /* accepted: the +0.0f lane of the reference's dot products, then the record */  \
+        "v_add_f32 %[aa], 0, %[du]\n"                                                    \
+        "v_add_f32 %[cc], 0, %[dv]\n"                                                    \
+        "v_add_f32 %[bb], 0, %[dt]\n"                                                    \
+        "v_mul_f32 %[hu], %[aa], %[idet]\n"                                              \
+        "v_mul_f32 %[hv], %[cc], %[idet]\n"                                              \
+        "v_mul_f32 %[ht], %[bb], %[idet]\n"                                              \
+        "v_mov_b32 %[hg], s55\n"                                                         \
+        "L_tri_next%=:\n"                                                                \
+        "s_and_b64 exec, %[EX], %[MI]\n"                                                 \
+        "s_sub_u32 %[cnt], %[cnt], 1\n"                                                  \
+        "s_cmp_lg_u32 %[cnt], 0\n"                                                       \
+        "s_cbranch_scc1 L_tri%=\n"                                                       \
+        "L_leaf_done%=:\n"                                                               \
+        "s_mov_b64 exec, %[EX]\n"                                                        \
+        "v_mov_b32 %[bb], %[node1]\n"                                                    \
+        "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"                                 \
+        "L_next%=:\n"                                                                    \
+        "s_add_u32 %[noff], %[noff], 32\n"                                               \
+        "s_add_u32 %[node], %[node], 1\n"                                                \
+        "s_cmp_lt_u32 %[node], %[nn]\n"                                                  \
+        "s_cbranch_scc1 L_node%=\n"                                                      \
+        "s_mov_b64 exec, %[EX]\n"                                                       
+#define ORION_WALK_OPERANDS \
+        : [nx] "+v"(next), [ht] "+v"(ht), [hu] "+v"(hu), [hv] "+v"(hv), [hg] "+v"(hg),                                          \
+          [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [det] "=&v"(det), [idet] "=&v"(idet),                                 \
+          [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz),                                                                       \
+          [aa] "=&v"(aa), [bb] "=&v"(bb), [cc] "=&v"(cc), [uu] "=&v"(uu), [du] "=&v"(du), [dv] "=&v"(dv), [dt] "=&v"(dt),       \
+          [EX] "=&s"(EX), [MI] "=&s"(MI), [PM] "=&s"(PM),                                                                       \
+          [noff] "=&s"(noff), [toff] "=&s"(toff), [cnt] "=&s"(cnt), [node] "=&s"(node), [node1] "=&s"(node1), [eps] "=&s"(eps)  \
+        : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z),                             \
+          [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z),                                                                    \
+          [nodes] "s"(S.nodes), [tris] "s"(S.tris), [nn] "s"(S.n_nodes), [fast] "s"(fast)                                       \
+        : "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc");                   
+
+template <bool QUICK_DIV>
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast) {
     float ht = h.t, hu = h.u, hv = h.v;
     uint32_t hg = h.gtri;
@@ -329,187 +581,16 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
     // SGPR temporaries: EX = lanes that entered, MI = lanes at the current node, PM = a stage's verdict
     unsigned long long EX, MI, PM;
     uint32_t noff, toff, cnt, node, node1, eps;
-    asm volatile(
-        "s_mov_b64 %[EX], exec\n"
-        "s_mov_b32 %[noff], 0\n"                       // byte offset of the node, steps by 32
-        "s_mov_b32 %[node], 0\n"
-        "s_mov_b32 %[eps], 0x358637bd\n"               // 1e-6f
-        "L_node%=:\n"
-        "v_cmp_eq_u32_e64 %[MI], %[node], %[nx]\n"
-        "s_cmp_eq_u64 %[MI], 0\n"
-        "s_cbranch_scc1 L_next%=\n"
-        "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n" // lo.xyz a | hi.xyz b
-        "s_add_u32 %[node1], %[node], 1\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "s_bitcmp1_b32 s59, 31\n"
-        "s_cbranch_scc1 L_leaf%=\n"
-        // ---- inner node: slab test, next = in ? node + 1 : skip
-        "v_sub_f32 %[aa], s52, %[ox]\n"
-        "v_sub_f32 %[bb], s56, %[ox]\n"
-        "v_sub_f32 %[cc], s53, %[oy]\n"
-        "v_sub_f32 %[uu], s57, %[oy]\n"
-        "v_sub_f32 %[du], s54, %[oz]\n"
-        "v_sub_f32 %[dv], s58, %[oz]\n"
-        "v_mul_f32 %[aa], %[aa], %[ix]\n"
-        "v_mul_f32 %[bb], %[bb], %[ix]\n"
-        "v_mul_f32 %[cc], %[cc], %[iy]\n"
-        "v_mul_f32 %[uu], %[uu], %[iy]\n"
-        "v_mul_f32 %[du], %[du], %[iz]\n"
-        "v_mul_f32 %[dv], %[dv], %[iz]\n"
-        "s_cmp_eq_u32 %[fast], 0\n"
-        "s_cbranch_scc1 L_slab_exact%=\n"
-        "v_min_f32 %[tx], %[aa], %[bb]\n"
-        "v_min_f32 %[ty], %[cc], %[uu]\n"
-        "v_min_f32 %[tz], %[du], %[dv]\n"
-        "v_max_f32 %[aa], %[aa], %[bb]\n"
-        "v_max_f32 %[cc], %[cc], %[uu]\n"
-        "v_max_f32 %[du], %[du], %[dv]\n"
-        "v_max3_f32 %[tx], %[tx], %[ty], %[tz]\n"      // tmin
-        "v_min3_f32 %[aa], %[aa], %[cc], %[du]\n"      // tmax
-        "s_branch L_slab_done%=\n"
-        // the reference's select order, for waves with a ray whose products can be NaN:
-        // lx = (t1<t2)?t1:t2, hx = (t1>t2)?t1:t2, tmin = (lx<m)?m:lx with m = (ly<lz)?lz:ly,
-        // tmax = (m2<hx)?m2:hx with m2 = (hz<hy)?hz:hy  (orion/AABB.hpp:79-99, orion/math.hpp:336-365)
-        "L_slab_exact%=:\n"
-        "v_cmp_lt_f32 vcc, %[aa], %[bb]\n s_nop 1\n v_cndmask_b32 %[tx], %[bb], %[aa], vcc\n"
-        "v_cmp_lt_f32 vcc, %[cc], %[uu]\n s_nop 1\n v_cndmask_b32 %[ty], %[uu], %[cc], vcc\n"
-        "v_cmp_lt_f32 vcc, %[du], %[dv]\n s_nop 1\n v_cndmask_b32 %[tz], %[dv], %[du], vcc\n"
-        "v_cmp_gt_f32 vcc, %[aa], %[bb]\n s_nop 1\n v_cndmask_b32 %[aa], %[bb], %[aa], vcc\n"
-        "v_cmp_gt_f32 vcc, %[cc], %[uu]\n s_nop 1\n v_cndmask_b32 %[cc], %[uu], %[cc], vcc\n"
-        "v_cmp_gt_f32 vcc, %[du], %[dv]\n s_nop 1\n v_cndmask_b32 %[du], %[dv], %[du], vcc\n"
-        "v_cmp_lt_f32 vcc, %[ty], %[tz]\n s_nop 1\n v_cndmask_b32 %[ty], %[ty], %[tz], vcc\n"
-        "v_cmp_lt_f32 vcc, %[tx], %[ty]\n s_nop 1\n v_cndmask_b32 %[tx], %[tx], %[ty], vcc\n"
-        "v_cmp_lt_f32 vcc, %[du], %[cc]\n s_nop 1\n v_cndmask_b32 %[cc], %[cc], %[du], vcc\n"
-        "v_cmp_lt_f32 vcc, %[cc], %[aa]\n s_nop 1\n v_cndmask_b32 %[aa], %[aa], %[cc], vcc\n"
-        "L_slab_done%=:\n"
-        "v_cmp_gt_f32 vcc, %[aa], %[tx]\n"
-        "v_cmp_lt_f32_e64 %[PM], 0, %[aa]\n"
-        "v_mov_b32 %[bb], %[node1]\n"
-        "v_mov_b32 %[cc], s55\n"
-        "s_and_b64 vcc, vcc, %[PM]\n"
-        "v_cndmask_b32_e32 %[bb], %[cc], %[bb], vcc\n"
-        "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"
-        "s_branch L_next%=\n"
-        // ---- leaf: its triangles, for the lanes that are here
-        "L_leaf%=:\n"
-        "s_and_b32 %[cnt], s59, 0x7fffffff\n"          // triangle count
-        "s_cbranch_scc0 L_leaf_done%=\n"
-        "s_mul_i32 %[toff], s55, 48\n"                 // byte offset of the leaf's first triangle
-        "s_and_b64 exec, %[EX], %[MI]\n"
-        "L_tri%=:\n"
-        "s_load_dwordx4 s[52:55], %[tris], %[toff]\n"              // v0.xyz gtri
-        "s_load_dwordx4 s[56:59], %[tris], %[toff] offset:0x10\n"  // e1.xyz
-        "s_load_dwordx4 s[60:63], %[tris], %[toff] offset:0x20\n"  // e2.xyz
-        "s_add_u32 %[toff], %[toff], 48\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        // pvec = cross(d, e2)
-        "v_mul_f32 %[px], s62, %[dy]\n"
-        "v_mul_f32 %[py], s60, %[dz]\n"
-        "v_mul_f32 %[pz], s61, %[dx]\n"
-        "v_fma_f32 %[px], -%[dz], s61, %[px]\n"
-        "v_fma_f32 %[py], -%[dx], s62, %[py]\n"
-        "v_fma_f32 %[pz], -%[dy], s60, %[pz]\n"
-        // det = dot(e1, pvec)
-        "v_mul_f32 %[aa], s56, %[px]\n"
-        "v_mul_f32 %[bb], s57, %[py]\n"
-        "v_mul_f32 %[cc], s58, %[pz]\n"
-        "v_add_f32 %[aa], %[aa], %[bb]\n"
-        "v_add_f32 %[det], %[aa], %[cc]\n"
-        "v_cmp_nlt_f32_e64 %[PM], |%[det]|, %[eps]\n"
-        "s_and_b64 exec, exec, %[PM]\n"
-        "s_cbranch_scc0 L_tri_next%=\n"
-        // inv_det = 1 / det, correctly rounded (q0 = aa, r = bb, q1 = cc, e = tx, m = dt)
-        "v_div_scale_f32 %[aa], %[PM], %[det], %[det], 1.0\n"
-        "v_rcp_f32 %[bb], %[aa]\n"
-        "v_div_scale_f32 %[cc], vcc, 1.0, %[det], 1.0\n"
-        "v_fma_f32 %[tx], -%[aa], %[bb], 1.0\n"
-        "v_fmac_f32 %[bb], %[tx], %[bb]\n"
-        "v_mul_f32 %[dt], %[cc], %[bb]\n"
-        "v_fma_f32 %[tx], -%[aa], %[dt], %[cc]\n"
-        "v_fmac_f32 %[dt], %[tx], %[bb]\n"
-        "v_fma_f32 %[aa], -%[aa], %[dt], %[cc]\n"
-        "v_div_fmas_f32 %[aa], %[aa], %[bb], %[dt]\n"
-        "v_div_fixup_f32 %[idet], %[aa], %[det], 1.0\n"
-        // tvec = o - v0, u = dot(tvec, pvec) * inv_det
-        "v_subrev_f32 %[tx], s52, %[ox]\n"
-        "v_subrev_f32 %[ty], s53, %[oy]\n"
-        "v_subrev_f32 %[tz], s54, %[oz]\n"
-        "v_mul_f32 %[aa], %[tx], %[px]\n"
-        "v_mul_f32 %[bb], %[ty], %[py]\n"
-        "v_mul_f32 %[cc], %[tz], %[pz]\n"
-        "v_add_f32 %[aa], %[aa], %[bb]\n"
-        "v_add_f32 %[du], %[aa], %[cc]\n"
-        "v_mul_f32 %[uu], %[du], %[idet]\n"
-        "v_cmp_ngt_f32 vcc, 0, %[uu]\n"
-        "v_cmp_nlt_f32_e64 %[PM], 1.0, %[uu]\n"
-        "s_and_b64 %[PM], vcc, %[PM]\n"
-        "s_and_b64 exec, exec, %[PM]\n"
-        "s_cbranch_scc0 L_tri_next%=\n"
-        // qvec = cross(tvec, e1) (in pvec's registers), v = dot(d, qvec) * inv_det
-        "v_mul_f32 %[px], s58, %[ty]\n"
-        "v_mul_f32 %[py], s56, %[tz]\n"
-        "v_mul_f32 %[pz], s57, %[tx]\n"
-        "v_fma_f32 %[px], -%[tz], s57, %[px]\n"
-        "v_fma_f32 %[py], -%[tx], s58, %[py]\n"
-        "v_fma_f32 %[pz], -%[ty], s56, %[pz]\n"
-        "v_mul_f32 %[aa], %[dx], %[px]\n"
-        "v_mul_f32 %[bb], %[dy], %[py]\n"
-        "v_mul_f32 %[cc], %[dz], %[pz]\n"
-        "v_add_f32 %[aa], %[aa], %[bb]\n"
-        "v_add_f32 %[dv], %[aa], %[cc]\n"
-        "v_mul_f32 %[aa], %[dv], %[idet]\n"
-        "v_cmp_ngt_f32 vcc, 0, %[aa]\n"
-        "v_add_f32 %[bb], %[uu], %[aa]\n"
-        "v_cmp_nlt_f32_e64 %[PM], 1.0, %[bb]\n"
-        "s_and_b64 %[PM], vcc, %[PM]\n"
-        "s_and_b64 exec, exec, %[PM]\n"
-        "s_cbranch_scc0 L_tri_next%=\n"
-        // t = dot(e2, qvec) * inv_det
-        "v_mul_f32 %[aa], s60, %[px]\n"
-        "v_mul_f32 %[bb], s61, %[py]\n"
-        "v_mul_f32 %[cc], s62, %[pz]\n"
-        "v_add_f32 %[aa], %[aa], %[bb]\n"
-        "v_add_f32 %[dt], %[aa], %[cc]\n"
-        "v_mul_f32 %[bb], %[dt], %[idet]\n"
-        "v_cmp_ngt_f32 vcc, %[bb], %[ht]\n"
-        "v_cmp_ngt_f32_e64 %[PM], 0, %[bb]\n"
-        "s_and_b64 %[PM], vcc, %[PM]\n"
-        "s_and_b64 exec, exec, %[PM]\n"
-        "s_cbranch_scc0 L_tri_next%=\n"
-        // accepted: the +0.0f lane of the reference's dot products, then the record
-        "v_add_f32 %[aa], 0, %[du]\n"
-        "v_add_f32 %[cc], 0, %[dv]\n"
-        "v_add_f32 %[bb], 0, %[dt]\n"
-        "v_mul_f32 %[hu], %[aa], %[idet]\n"
-        "v_mul_f32 %[hv], %[cc], %[idet]\n"
-        "v_mul_f32 %[ht], %[bb], %[idet]\n"
-        "v_mov_b32 %[hg], s55\n"
-        "L_tri_next%=:\n"
-        "s_and_b64 exec, %[EX], %[MI]\n"
-        "s_sub_u32 %[cnt], %[cnt], 1\n"
-        "s_cmp_lg_u32 %[cnt], 0\n"
-        "s_cbranch_scc1 L_tri%=\n"
-        "L_leaf_done%=:\n"
-        "s_mov_b64 exec, %[EX]\n"
-        "v_mov_b32 %[bb], %[node1]\n"
-        "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"
-        "L_next%=:\n"
-        "s_add_u32 %[noff], %[noff], 32\n"
-        "s_add_u32 %[node], %[node], 1\n"
-        "s_cmp_lt_u32 %[node], %[nn]\n"
-        "s_cbranch_scc1 L_node%=\n"
-        "s_mov_b64 exec, %[EX]\n"
-        : [nx] "+v"(next), [ht] "+v"(ht), [hu] "+v"(hu), [hv] "+v"(hv), [hg] "+v"(hg),
-          [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [det] "=&v"(det), [idet] "=&v"(idet),
-          [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz),
-          [aa] "=&v"(aa), [bb] "=&v"(bb), [cc] "=&v"(cc), [uu] "=&v"(uu), [du] "=&v"(du), [dv] "=&v"(dv), [dt] "=&v"(dt),
-          [EX] "=&s"(EX), [MI] "=&s"(MI), [PM] "=&s"(PM),
-          [noff] "=&s"(noff), [toff] "=&s"(toff), [cnt] "=&s"(cnt), [node] "=&s"(node), [node1] "=&s"(node1), [eps] "=&s"(eps)
-        : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z),
-          [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z),
-          [nodes] "s"(S.nodes), [tris] "s"(S.tris), [nn] "s"(S.n_nodes), [fast] "s"(fast)
-        : "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc");
+    fast = __builtin_amdgcn_readfirstlane(fast);
+    if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS
+    else asm volatile(ORION_WALK_BEFORE_DIV ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS
     h.t = ht; h.u = hu; h.v = hv; h.gtri = hg;
 }
+
+#undef ORION_WALK_BEFORE_DIV
+#undef ORION_WALK_DIV_EXACT
+#undef ORION_WALK_DIV_QUICK
+#undef ORION_WALK_AFTER_DIV
+#undef ORION_WALK_OPERANDS
 
 } // namespace orion_dev

@@ -468,6 +468,19 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     v.n_nodes = (uint32_t)nodes.size(); v.n_tris = (uint32_t)tris.size();
     v.n_meshes = n_meshes; v.n_emissive = (uint32_t)emissive.size();
     if (!items.empty()) { if ((rc = upload(s, items, &v.items))) return bail(rc); v.n_items = 64; }
+    {   // |det| = |e1 . (d x e2)| <= 6 D E^2 for direction components up to D and edge components up to E;
+        // D < 2^122 / E^2 keeps it (and every intermediate, rounding included) below 2^126 with room to spare
+        double E = 0.0;
+        bool finite = true;
+        for (const Tri& t : tris)
+            for (int k = 0; k < 3; k++) {
+                finite = finite && std::isfinite(t.e1[k]) && std::isfinite(t.e2[k]);
+                E = std::fmax(E, std::fmax(std::fabs((double)t.e1[k]), std::fabs((double)t.e2[k])));
+            }
+        double bound = (finite && E > 0.0) ? std::ldexp(1.0, 122) / (E * E) : (finite ? std::ldexp(1.0, 126) : 0.0);
+        if (bound > std::ldexp(1.0, 126)) bound = std::ldexp(1.0, 126);
+        v.dir_bound = (float)(bound * (1.0 - 1e-6));
+    }
     s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
     for (const Mesh& dm : dmeshes) s->mesh_tri_base.push_back(dm.tri_base);
     *out = s;

@@ -443,6 +443,49 @@ def test_exact_ties_resolve_like_the_reference(gpu, n_meshes, per_mesh, modes):
     sc.close()
 
 
+def _edge_bound(model):
+    """The direction bound the scene upload derives: 2^122 / E^2 (E = largest edge component), at most 2^126."""
+    E = 0.0
+    for m in model.meshes:
+        v = m.vertices[m.indices.reshape(-1, 3), 0:3].astype(np.float32)
+        E = max(E, float(np.abs(v[:, 1] - v[:, 0]).max()), float(np.abs(v[:, 2] - v[:, 0]).max()))
+    return min(2.0 ** 122 / (E * E), 2.0 ** 126)
+
+
+@pytest.mark.parametrize("name,modes", [("cornell", (1, 2, 3)), ("soup", (1,))])
+def test_quick_reciprocals_return_the_divisions_bits(gpu, name, modes):
+    """1/det and 1/dir are computed as reciprocal estimate + one Newton step wherever that returns
+    the bits of the IEEE division (normal divisors below 2^126), and by division elsewhere; which
+    one a wave takes depends on the magnitude of its rays' directions.  Scaled rays on both sides
+    of every switch-over must keep matching the oracle (which divides) bit for bit."""
+    model = conftest.load_model(name)
+    sc = scene_for(gpu, name)
+    orc = oracle_for(name)
+    n = 1 << 15
+    o, d0 = raygen.box_rays(model, n, seed=33)
+    dmax = float(np.abs(d0).max())
+    bound = _edge_bound(model)
+    scales = [2.0 ** -20, 1.0, 2.0 ** 60, 0.5 * bound / dmax, 0.97 * bound / dmax, 1.03 * bound / dmax, 2.0 ** 125 / dmax, 2.0 ** 127 / dmax]
+    for k, sfac in enumerate(scales):
+        d = (d0.astype(np.float64) * sfac).astype(np.float32)
+        if k % 2:                       # some waves with components outside the normal range
+            d[::257, 0] = 0.0
+            d[3::509, 1] = np.float32(1e-41)
+            d[7::1021, 2] = np.float32(2.0 ** -126)
+        assert np.isfinite(d).all()
+        oid, otuv = orc.closest_hit(o, d, threads=8)
+        if sfac in (1.0, 2.0 ** 60):    # (tiny directions fall under the |det| < 1e-6 rejection)
+            assert (oid[:, 0] != gpu.INVALID).mean() > 0.3
+        for mode in modes:
+            sc.set_option("traversal", mode)
+            ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+            assert np.array_equal(ids, oid), f"{name} mode {mode} scale {sfac:g}: ids"
+            assert np.array_equal(bits(tuv), bits(otuv)), f"{name} mode {mode} scale {sfac:g}: t,u,v"
+            occ = sc.any_hit(o, d)
+            assert np.array_equal(occ.astype(bool), oid[:, 0] != gpu.INVALID), f"{name} mode {mode} scale {sfac:g}: any hit"
+    sc.set_option("traversal", 0)
+
+
 def test_batching_and_repetition_change_nothing(gpu):
     """How a render call is cut into batches (option batch_paths), and running it twice, must not
     move a bit: samples are independent and are summed per pixel in ascending sample order."""
