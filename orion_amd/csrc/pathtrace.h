@@ -370,8 +370,8 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
                 const float cc = tpl_max(tpl_max(kd.x, kd.y), kd.z);
                 const Words4 r = philox4x32_10(pixel, sample, depth, kBlockBounce, F.seed_lo, F.seed_hi);
                 if (!(u01(r.w[0]) > cc)) {
-                    const float sin_theta = sqrtf(u01(r.w[1]));
-                    const float cos_theta = sqrtf(1 - sin_theta * sin_theta);
+                    const float sin_theta = sqrt_quick(u01(r.w[1]));   // u01 lies in (2^-24, 1): always in the short form's range
+                    const float cos_theta = sqrt_exact(1 - sin_theta * sin_theta);
                     const float psi = u01(r.w[2]) * 2.0f * 3.1415926535f;
                     V3 tangent = cross(normal, mk(0.0f, 1.0f, 0.0f));
                     if (dot(tangent, tangent) == 0.0f) tangent = cross(normal, mk(0.0f, 0.0f, 1.0f));

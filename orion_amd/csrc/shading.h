@@ -39,10 +39,31 @@ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32
 __device__ __forceinline__ float u01(uint32_t w) { return ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-07f; }
 
 // --- helpers ------------------------------------------------------------------
+// sqrtf(x) as reciprocal-square-root estimate and one correction step.  For every float with
+// 2^-102 <= x <= FLT_MAX this returns the bits of the correctly rounded square root (checked for
+// each of them, tools/micro/sqrt_exact.hip) in 5 instructions instead of about 20; for zero,
+// smaller values and infinity it does not.
+__device__ __forceinline__ float sqrt_quick(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    return fmaf(fmaf(-g, g, x), h, g);
+}
+__device__ __forceinline__ bool sqrt_quick_ok(float x) { return x >= 1.97215226e-31f && x <= 3.40282347e+38f; }   // 2^-102 .. FLT_MAX
+
+// sqrtf(x), with the short form when every active lane's argument allows it (the same bits either way).
+__device__ __forceinline__ float sqrt_exact(float x) {
+    if (__all(sqrt_quick_ok(x))) return sqrt_quick(x);
+    return sqrtf(x);
+}
+
 // normalize (orion/math.hpp:128-132): the reference multiplies by rsqrtps, a
-// hardware-specific approximation; this build uses the exact 1/sqrt.
+// hardware-specific approximation; this build uses the exact 1/sqrt.  (A square root in
+// sqrt_quick's range lies in [2^-51, 2^64], inside recip_quick's.)
 __device__ __forceinline__ V3 normalize(V3 a) {
-    float r = 1.0f / sqrtf(dot(a, a));
+    const float x = dot(a, a);
+    float r;
+    if (__all(sqrt_quick_ok(x))) r = recip_quick(sqrt_quick(x));
+    else r = 1.0f / sqrtf(x);
     return a * r;
 }
 

@@ -443,6 +443,18 @@ def test_exact_ties_resolve_like_the_reference(gpu, n_meshes, per_mesh, modes):
     sc.close()
 
 
+def test_quick_math_claims_hold_for_every_float(gpu):
+    """The short reciprocal and square-root forms are used where they return the bits of the
+    division / sqrtf.  That claim is about 2^32 arguments and is checked on all of them, with the
+    kernels' own device functions (tools/micro/quick_math_claims.hip, built by build())."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "orion_amd", "quick_math_claims")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "recip_quick mismatches: 0  sqrt_quick mismatches: 0  guard errors: 0" in r.stdout
+
+
 def _edge_bound(model):
     """The direction bound the scene upload derives: 2^122 / E^2 (E = largest edge component), at most 2^126."""
     E = 0.0

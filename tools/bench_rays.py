@@ -18,7 +18,7 @@ def main():
     import torch
     from orion_amd import api
     scenes = sys.argv[1:] or ["cornell", "hindu", "nanosuit", "soup"]
-    n = 1 << 22
+    n = 1 << int(os.environ.get("RAYS_LOG2", "22"))
     for name in scenes:
         model = conftest.load_model(name)
         sc = api.Scene(model, device=0)
@@ -66,6 +66,10 @@ def main():
                 for nm, k2 in (("R4 tile tri", key), ("R4 tile tri+q", key * 4 + quad)):
                     o_t = np.lexsort((k2, tile))
                     batches[nm] = (o4[o_t], d4[o_t])
+                # ... and with larger tiles
+                for size in (65536, 1024, 16384, 4096, 2048):
+                    o_t = np.lexsort((key, np.arange(n) // size))
+                    batches[f"R4 tile {size}"] = (o4[o_t], d4[o_t])
                 # ... and inside each surface by direction octant
                 dd = d2[perm]
                 octant = (dd[:, 0] > 0).astype(np.int64) | ((dd[:, 1] > 0).astype(np.int64) << 1) | ((dd[:, 2] > 0).astype(np.int64) << 2)
