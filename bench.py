@@ -4,7 +4,9 @@
 
 A step renders `--spp-per-step` samples of every pixel on each rank (ranks own disjoint sample
 ranges; weak scaling) into a device-resident accumulator, followed for N > 1 by one RCCL sum of
-the accumulators -- the only exchange the workload has.  value = pixel-samples/s over all ranks.
+the accumulators -- the only exchange the workload has.  The sum runs asynchronously while the next
+step renders into a second accumulator; the timed region ends when every sum has finished.
+value = pixel-samples/s over all ranks.
 
     python bench.py --gpus 1 --steps 4 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -107,29 +109,35 @@ def main():
         scene.set_option("tail_paths", args.tail_paths)
     if args.overlap_below >= 0:
         scene.set_option("overlap_below", args.overlap_below)
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    accums = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
+    pending = [None] * len(accums)
     spp = args.spp_per_step
 
     def step(index):
+        k = index % len(accums)
+        if pending[k] is not None:       # the sum that last used this accumulator
+            pending[k].wait(); pending[k] = None
+        accums[k].zero_()
         base = (index * world + rank) * spp
-        scene.render(cam, W, H, base, base + spp, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accum)
-        if world > 1:
-            dist.all_reduce(accum)   # the frame's one exchange: sum of the radiance accumulators
+        scene.render(cam, W, H, base, base + spp, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accums[k])
+        if world > 1:                    # the frame's one exchange: sum of the radiance accumulators
+            pending[k] = dist.all_reduce(accums[k], async_op=True)
 
     def fence():
+        for k, w in enumerate(pending):
+            if w is not None:
+                w.wait(); pending[k] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        accum.zero_()
         step(i)
     scene.profile(not args.no_profile)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        accum.zero_()
         step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0

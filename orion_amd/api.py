@@ -119,6 +119,17 @@ def camera_vectors(eye, look_at, up, y_view: float, aspect: float) -> np.ndarray
     return np.array(list(cam.eye) + list(cam.front) + list(cam.right) + list(cam.up), np.float32)
 
 
+def _settle(*tensors) -> None:
+    """The library runs on streams of its own and its calls return when their work is done, but it
+    knows nothing of the torch streams that may still be writing (or reading) the device buffers
+    handed to it: wait for the current torch stream before the call."""
+    for t in tensors:
+        if t is not None and _is_torch(t):
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+            return
+
+
 class Scene:
     """A model flattened and resident in HBM (orion_hip_scene_create)."""
 
@@ -183,6 +194,7 @@ class Scene:
             assert org.dtype == torch.float32 and dir.dtype == torch.float32 and org.is_contiguous() and dir.is_contiguous()
             if out is None:
                 out = torch.empty((n, 5), dtype=torch.int32, device=org.device)
+            _settle(org)
             _check(lib().orion_hip_closest_hit(self.h, org.data_ptr(), dir.data_ptr(), n, out.data_ptr()))
             return out
         o = np.ascontiguousarray(org, np.float32).reshape(-1, 3); d = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
@@ -198,6 +210,7 @@ class Scene:
             n = org.shape[0]
             if out is None:
                 out = torch.empty(n, dtype=torch.uint8, device=org.device)
+            _settle(org)
             _check(lib().orion_hip_any_hit(self.h, org.data_ptr(), dir.data_ptr(), n, out.data_ptr()))
             return out
         o = np.ascontiguousarray(org, np.float32).reshape(-1, 3); d = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
@@ -224,6 +237,7 @@ class Scene:
             p.tile_x0, p.tile_y0, p.tile_x1, p.tile_y1 = tile
         if accum is None:
             accum = np.zeros((height, width, 4), np.float32)
+        _settle(accum)
         _check(lib().orion_hip_render(self.h, C.byref(cam), C.byref(p), _ptr(accum)))
         return accum
 
