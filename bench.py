@@ -32,6 +32,7 @@ MAX_DEPTH, LIGHT_SAMPLES, FULL_SPP = 100, 2, 2048
 CAMERA = ([-0.10141, 1, 3.00498], [-0.10141, 1, 2.00498], [0, 1, 0], 1.0)   # assets/cornell-box.rtc
 PUBLISHED_SAMPLES_PER_S = 1920 * 1080 * 2048 / 5126.4                        # reference README.md:38-46
 HBM_PEAK_GBS = 8000.0                                                        # MI355X HBM3E peak
+VALU_PEAK_GINSTR_S = 1024 * 2.4 / 2.84                                       # measured sustained wave64 VALU issue rate, G/s
 # Algorithmic queue bytes: 32 B ray record read + 32 B hit record written per closest-hit query;
 # a shaded path vertex adds L*E such queries for its light samples and 48 B + 48 B of path state.
 BYTES_PER_RAY = 64
@@ -197,6 +198,14 @@ def main():
                                        "sustained 2.84), not by HBM.  Two batches are in flight at batch boundaries, so a launch's "
                                        "duration includes the time it shares the chip with the other batch's launches."}
             out["kernels"] = kern
+            if all("valu_wave_instructions_per_item" in pmc.get(k, {}) for k in kern):
+                # what actually bounds the step: vector-instruction issue.  Instructions per ray / vertex from the
+                # counter passes in profiles/, the chip's sustained rate from tools/micro/valu_rate.hip
+                # (one wave64 instruction per 2.84 cycles per SIMD, 1024 SIMDs at 2.4 GHz).
+                instr = sum(pmc[k]["valu_wave_instructions_per_item"] * kern[k]["units"] for k in kern)
+                out["issue"] = {"bound": "valu issue", "achieved": instr / dt / 1e9, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave64 instructions/s",
+                                "frac": instr / dt / 1e9 / VALU_PEAK_GINSTR_S,
+                                "note": "k_extend + k_shade vector instructions of rank 0 over the timed region / wall time"}
             rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
             out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
                            "Mrays_per_s_per_gpu": rays / dt / 1e6,

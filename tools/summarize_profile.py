@@ -74,6 +74,8 @@ def main():
             if k in agg and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k] and n:
                 traffic[k] = {"hbm_read_bytes_per_item": agg[k]["FETCH_SIZE"] * 1024 * 2 / n,
                               "hbm_write_bytes_per_item": agg[k]["WRITE_SIZE"] * 1024 / n, "items": n, "note": note}
+                if "SQ_INSTS_VALU" in agg[k]:   # wave64 vector instructions issued per item
+                    traffic[k]["valu_wave_instructions_per_item"] = agg[k]["SQ_INSTS_VALU"] / n
         json.dump(traffic, open(sys.argv[3], "w"), indent=1)
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
