@@ -19,10 +19,16 @@ def main():
     from orion_amd import api
     print("| config | resolution | depth | traversal | spp timed | Msamples/s | Mrays/s | projected wall (config spp) |")
     print("|---|---|---|---|---|---|---|---|")
+    only = sys.argv[1:]
     for name, spp_full, ls, spp in CONFIGS:
+        if only and name not in only:
+            continue
         fr = api.load_frame(os.path.join(ROOT, "configs", name + ".rtc"), load_textures=False)
         W, H = fr.rtc.xres, fr.rtc.yres
         sc = api.Scene(fr.model, device=0)
+        forced = int(os.environ.get("TRAVERSAL", "0"))     # A/B runs: 1 per-lane, 2 wave-synchronous
+        if forced:
+            sc.set_option("traversal", forced)
         acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
         sc.render(fr.camera12, W, H, 0, min(4, spp), ls, fr.rtc.recursion_level, seed=1, lights=fr.rtc.lights, accum=acc)
         sc.profile(True)
@@ -34,7 +40,7 @@ def main():
         st = sc.profile_read()
         rays = st["closest_hit"]["items"] + st["shadow"]["items"]
         n_ops = sum(len(m.nodes) for m in fr.model.meshes)
-        mode = "wave-synchronous" if n_ops <= 64 else "per-lane"
+        mode = {1: "per-lane", 2: "wave-synchronous"}.get(forced) or ("wave-synchronous" if n_ops <= 64 else "per-lane")
         print(f"| {name} | {W}x{H} | {fr.rtc.recursion_level} | {mode} | {spp} | {W * H * spp / dt / 1e6:.1f} | {rays / dt / 1e6:.1f} | "
               f"{W * H * spp_full / (W * H * spp / dt):.2f} s |", flush=True)
         sc.close()
