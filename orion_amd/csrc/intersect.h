@@ -440,16 +440,17 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "s_branch L_next%=\n"                                                                               \
         /* ---- leaf: its triangles, for the lanes that are here */                                         \
         "L_leaf%=:\n"                                                                                       \
-        "s_and_b32 %[cnt], s59, 0x7fffffff\n"  /* triangle count */                                         \
-        "s_cbranch_scc0 L_leaf_done%=\n"                                                                    \
-        "s_mul_i32 %[toff], s55, 48\n"  /* byte offset of the leaf's first triangle */                      \
-        "s_and_b64 exec, %[EX], %[MI]\n"                                                                    \
-        "L_tri%=:\n"                                                                                        \
-        "s_load_dwordx4 s[52:55], %[tris], %[toff]\n"  /* v0.xyz gtri */                                    \
-        "s_load_dwordx4 s[56:59], %[tris], %[toff] offset:0x10\n"  /* e1.xyz */                             \
-        "s_load_dwordx4 s[60:63], %[tris], %[toff] offset:0x20\n"  /* e2.xyz */                             \
-        "s_add_u32 %[toff], %[toff], 48\n"                                                                  \
-        "s_waitcnt lgkmcnt(0)\n"                                                                            \
+        "s_and_b32 %[cnt], s59, 0x7fffffff\n"  /* triangle count */ \
+        "s_cbranch_scc0 L_leaf_done%=\n" \
+        "s_mul_i32 %[toff], s55, 48\n"  /* byte offset of the leaf's first triangle */ \
+        "s_mul_i32 %[cnt], %[cnt], 48\n" \
+        "s_add_u32 %[cnt], %[cnt], %[toff]\n"  /* ... and of the end of its last */ \
+        "s_and_b64 exec, %[EX], %[MI]\n" \
+        "L_tri%=:\n" \
+        "s_load_dwordx8 s[52:59], %[tris], %[toff]\n"  /* v0.xyz gtri e1.xyz */ \
+        "s_load_dwordx4 s[60:63], %[tris], %[toff] offset:0x20\n"  /* e2.xyz */ \
+        "s_add_u32 %[toff], %[toff], 48\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
         /* pvec = cross(d, e2) */                                                                           \
         "v_mul_f32 %[px], s62, %[dy]\n"                                                                     \
         "v_mul_f32 %[py], s60, %[dz]\n"                                                                     \
@@ -463,9 +464,8 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "v_mul_f32 %[cc], s58, %[pz]\n"                                                                     \
         "v_add_f32 %[aa], %[aa], %[bb]\n"                                                                   \
         "v_add_f32 %[det], %[aa], %[cc]\n"                                                                  \
-        "v_cmp_nlt_f32_e64 %[PM], |%[det]|, %[eps]\n"                                                       \
-        "s_and_b64 exec, exec, %[PM]\n"                                                                     \
-        "s_cbranch_scc0 L_tri_next%=\n"                                                                    
+        "v_cmpx_nlt_f32_e64 vcc, |%[det]|, %[eps]\n"  /* the comparison narrows the execution mask itself */ \
+        /* (no exit here: a whole wave parallel to a triangle is too rare to pay for a branch per test) */
 #define ORION_WALK_DIV_EXACT \
         /* inv_det = 1 / det, correctly rounded (q0 = aa, r = bb, q1 = cc, e = tx, m = dt) */  \
         "v_div_scale_f32 %[aa], %[PM], %[det], %[det], 1.0\n"                                  \
@@ -501,11 +501,9 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "v_add_f32 %[aa], %[aa], %[bb]\n"                                                \
         "v_add_f32 %[du], %[aa], %[cc]\n"                                                \
         "v_mul_f32 %[uu], %[du], %[idet]\n"                                              \
-        "v_cmp_ngt_f32 vcc, 0, %[uu]\n"                                                  \
-        "v_cmp_nlt_f32_e64 %[PM], 1.0, %[uu]\n"                                          \
-        "s_and_b64 %[PM], vcc, %[PM]\n"                                                  \
-        "s_and_b64 exec, exec, %[PM]\n"                                                  \
-        "s_cbranch_scc0 L_tri_next%=\n"                                                  \
+        "v_cmpx_ngt_f32 vcc, 0, %[uu]\n" \
+        "v_cmpx_nlt_f32 vcc, 1.0, %[uu]\n" \
+        "s_cbranch_execz L_tri_next%=\n" \
         /* qvec = cross(tvec, e1) (in pvec's registers), v = dot(d, qvec) * inv_det */   \
         "v_mul_f32 %[px], s58, %[ty]\n"                                                  \
         "v_mul_f32 %[py], s56, %[tz]\n"                                                  \
@@ -519,12 +517,10 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "v_add_f32 %[aa], %[aa], %[bb]\n"                                                \
         "v_add_f32 %[dv], %[aa], %[cc]\n"                                                \
         "v_mul_f32 %[aa], %[dv], %[idet]\n"                                              \
-        "v_cmp_ngt_f32 vcc, 0, %[aa]\n"                                                  \
-        "v_add_f32 %[bb], %[uu], %[aa]\n"                                                \
-        "v_cmp_nlt_f32_e64 %[PM], 1.0, %[bb]\n"                                          \
-        "s_and_b64 %[PM], vcc, %[PM]\n"                                                  \
-        "s_and_b64 exec, exec, %[PM]\n"                                                  \
-        "s_cbranch_scc0 L_tri_next%=\n"                                                  \
+        "v_add_f32 %[bb], %[uu], %[aa]\n" \
+        "v_cmpx_ngt_f32 vcc, 0, %[aa]\n" \
+        "v_cmpx_nlt_f32 vcc, 1.0, %[bb]\n" \
+        "s_cbranch_execz L_tri_next%=\n" \
         /* t = dot(e2, qvec) * inv_det */                                                \
         "v_mul_f32 %[aa], s60, %[px]\n"                                                  \
         "v_mul_f32 %[bb], s61, %[py]\n"                                                  \
@@ -532,11 +528,9 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "v_add_f32 %[aa], %[aa], %[bb]\n"                                                \
         "v_add_f32 %[dt], %[aa], %[cc]\n"                                                \
         "v_mul_f32 %[bb], %[dt], %[idet]\n"                                              \
-        "v_cmp_ngt_f32 vcc, %[bb], %[ht]\n"                                              \
-        "v_cmp_ngt_f32_e64 %[PM], 0, %[bb]\n"                                            \
-        "s_and_b64 %[PM], vcc, %[PM]\n"                                                  \
-        "s_and_b64 exec, exec, %[PM]\n"                                                  \
-        "s_cbranch_scc0 L_tri_next%=\n"                                                  \
+        "v_cmpx_ngt_f32 vcc, %[bb], %[ht]\n" \
+        "v_cmpx_ngt_f32 vcc, 0, %[bb]\n" \
+        "s_cbranch_execz L_tri_next%=\n" \
         /* accepted: the +0.0f lane of the reference's dot products, then the record */  \
         "v_add_f32 %[aa], 0, %[du]\n"                                                    \
         "v_add_f32 %[cc], 0, %[dv]\n"                                                    \
@@ -546,10 +540,9 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "v_mul_f32 %[ht], %[bb], %[idet]\n"                                              \
         "v_mov_b32 %[hg], s55\n"                                                         \
         "L_tri_next%=:\n"                                                                \
-        "s_and_b64 exec, %[EX], %[MI]\n"                                                 \
-        "s_sub_u32 %[cnt], %[cnt], 1\n"                                                  \
-        "s_cmp_lg_u32 %[cnt], 0\n"                                                       \
-        "s_cbranch_scc1 L_tri%=\n"                                                       \
+        "s_and_b64 exec, %[EX], %[MI]\n" \
+        "s_cmp_lt_u32 %[toff], %[cnt]\n" \
+        "s_cbranch_scc1 L_tri%=\n" \
         "L_leaf_done%=:\n"                                                               \
         "s_mov_b64 exec, %[EX]\n"                                                        \
         "v_mov_b32 %[bb], %[node1]\n"                                                    \
