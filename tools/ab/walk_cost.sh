@@ -12,7 +12,7 @@ for r in csv.DictReader(open("$out/wc/p_counter_collection.csv")):
     if "k_closest_api" in r["Kernel_Name"]:
         rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
-for i in ids[-3:]:
+for i in ids[-1:]:
     c = rows[i]
     print(i, {k: round(v / c["SQ_WAVES"], 1) for k, v in c.items() if k != "SQ_WAVES"}, "waves", int(c["SQ_WAVES"]))
 PY

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Closest-hit throughput (Mrays/s) of the traversal kernels on device-resident ray batches,
-timed with the library's HIP events.  Usage: python tools/bench_rays.py [scene ...]"""
+timed with the library's HIP events.  Usage: python tools/bench_rays.py [scene ...]
+Environment: RAYS_LOG2 (batch size, default 22), RAYS_ONLY (name of the one batch to run)."""
 import os
 import sys
 import time
@@ -79,7 +80,10 @@ def main():
             if tag == "wave" and model.n_triangles > 2000:
                 continue
             sc.set_option("traversal", mode)
+            only = os.environ.get("RAYS_ONLY")                # run just this batch (counter passes)
             for bname, (o, d) in batches.items():
+                if only and bname != only:
+                    continue
                 to, td = torch.from_numpy(np.ascontiguousarray(o)).cuda(), torch.from_numpy(np.ascontiguousarray(d)).cuda()
                 out = torch.empty((len(o), 5), dtype=torch.int32, device="cuda")
                 sc.closest_hit(to, td, out)
