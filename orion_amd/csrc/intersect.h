@@ -378,17 +378,17 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 // node or triangle being processed.
 // ---------------------------------------------------------------------------
 #define ORION_WALK_BEFORE_DIV \
-        "s_mov_b64 %[EX], exec\n"                                                                           \
-        "s_mov_b32 %[noff], 0\n"  /* byte offset of the node, steps by 32 */                                \
-        "s_mov_b32 %[node], 0\n"                                                                            \
-        "s_mov_b32 %[eps], 0x358637bd\n"  /* 1e-6f */                                                       \
-        "L_node%=:\n"                                                                                       \
-        "v_cmp_eq_u32_e64 %[MI], %[node], %[nx]\n"                                                          \
-        "s_cmp_eq_u64 %[MI], 0\n"                                                                           \
-        "s_cbranch_scc1 L_next%=\n"                                                                         \
-        "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n"  /* lo.xyz a | hi.xyz b */                           \
-        "s_add_u32 %[node1], %[node], 1\n"                                                                  \
-        "s_waitcnt lgkmcnt(0)\n"                                                                            \
+        "s_mov_b64 %[EX], exec\n" \
+        "s_mov_b32 %[noff], 0\n"  /* byte offset of the node, steps by 32; the lanes' `next` is kept in the same unit */ \
+        "s_lshl_b32 %[nend], %[nn], 5\n" \
+        "v_lshlrev_b32 %[nx], 5, %[nx]\n"  /* (kInvalid stays out of range) */ \
+        "s_mov_b32 %[eps], 0x358637bd\n"  /* 1e-6f */ \
+        "L_node%=:\n" \
+        "v_cmp_eq_u32_e64 %[MI], %[noff], %[nx]\n" \
+        "s_cmp_eq_u64 %[MI], 0\n" \
+        "s_cbranch_scc1 L_next%=\n" \
+        "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n"  /* lo.xyz a | hi.xyz b */ \
+        "s_waitcnt lgkmcnt(0)\n" \
         "s_bitcmp1_b32 s59, 31\n"                                                                           \
         "s_cbranch_scc1 L_leaf%=\n"                                                                         \
         /* ---- inner node: slab test, next = in ? node + 1 : skip */                                       \
@@ -432,9 +432,9 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "L_slab_done%=:\n"                                                                                  \
         "v_cmp_gt_f32 vcc, %[aa], %[tx]\n"                                                                  \
         "v_cmp_lt_f32_e64 %[PM], 0, %[aa]\n"                                                                \
-        "v_mov_b32 %[bb], %[node1]\n"                                                                       \
-        "v_mov_b32 %[cc], s55\n"                                                                            \
-        "s_and_b64 vcc, vcc, %[PM]\n"                                                                       \
+        "v_add_u32_e64 %[bb], %[noff], 32\n" \
+        "v_lshlrev_b32 %[cc], 5, s55\n" \
+        "s_and_b64 vcc, vcc, %[PM]\n" \
         "v_cndmask_b32_e32 %[bb], %[cc], %[bb], vcc\n"                                                      \
         "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"                                                    \
         "s_branch L_next%=\n"                                                                               \
@@ -544,14 +544,13 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "s_cmp_lt_u32 %[toff], %[cnt]\n" \
         "s_cbranch_scc1 L_tri%=\n" \
         "L_leaf_done%=:\n"                                                               \
-        "s_mov_b64 exec, %[EX]\n"                                                        \
-        "v_mov_b32 %[bb], %[node1]\n"                                                    \
-        "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"                                 \
-        "L_next%=:\n"                                                                    \
-        "s_add_u32 %[noff], %[noff], 32\n"                                               \
-        "s_add_u32 %[node], %[node], 1\n"                                                \
-        "s_cmp_lt_u32 %[node], %[nn]\n"                                                  \
-        "s_cbranch_scc1 L_node%=\n"                                                      \
+        "s_mov_b64 exec, %[EX]\n" \
+        "v_add_u32_e64 %[bb], %[noff], 32\n" \
+        "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n" \
+        "L_next%=:\n" \
+        "s_add_u32 %[noff], %[noff], 32\n" \
+        "s_cmp_lt_u32 %[noff], %[nend]\n" \
+        "s_cbranch_scc1 L_node%=\n" \
         "s_mov_b64 exec, %[EX]\n"                                                       
 #define ORION_WALK_OPERANDS \
         : [nx] "+v"(next), [ht] "+v"(ht), [hu] "+v"(hu), [hv] "+v"(hv), [hg] "+v"(hg),                                          \
@@ -559,7 +558,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
           [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz),                                                                       \
           [aa] "=&v"(aa), [bb] "=&v"(bb), [cc] "=&v"(cc), [uu] "=&v"(uu), [du] "=&v"(du), [dv] "=&v"(dv), [dt] "=&v"(dt),       \
           [EX] "=&s"(EX), [MI] "=&s"(MI), [PM] "=&s"(PM),                                                                       \
-          [noff] "=&s"(noff), [toff] "=&s"(toff), [cnt] "=&s"(cnt), [node] "=&s"(node), [node1] "=&s"(node1), [eps] "=&s"(eps)  \
+          [noff] "=&s"(noff), [toff] "=&s"(toff), [cnt] "=&s"(cnt), [nend] "=&s"(nend), [eps] "=&s"(eps)  \
         : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z),                             \
           [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z),                                                                    \
           [nodes] "s"(S.nodes), [tris] "s"(S.tris), [nn] "s"(S.n_nodes), [fast] "s"(fast)                                       \
@@ -573,7 +572,7 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
     float px, py, pz, det, idet, tx, ty, tz, aa, bb, cc, uu, du, dv, dt;
     // SGPR temporaries: EX = lanes that entered, MI = lanes at the current node, PM = a stage's verdict
     unsigned long long EX, MI, PM;
-    uint32_t noff, toff, cnt, node, node1, eps;
+    uint32_t noff, nend, toff, cnt, eps;
     fast = __builtin_amdgcn_readfirstlane(fast);
     if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS
     else asm volatile(ORION_WALK_BEFORE_DIV ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS
