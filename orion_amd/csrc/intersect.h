@@ -437,7 +437,11 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "s_and_b64 vcc, vcc, %[PM]\n" \
         "v_cndmask_b32_e32 %[bb], %[cc], %[bb], vcc\n"                                                      \
         "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n"                                                    \
-        "s_branch L_next%=\n"                                                                               \
+        "s_and_b64 %[PM], vcc, %[MI]\n"                                                                     \
+        "s_cbranch_scc1 L_next%=\n"                                                                         \
+        /* no lane enters: the walk resumes at the skip link (lanes get into a subtree through its root only) */ \
+        "s_lshl_b32 %[noff], s55, 5\n"                                                                      \
+        "s_branch L_test%=\n"                                                                               \
         /* ---- leaf: its triangles, for the lanes that are here */                                         \
         "L_leaf%=:\n"                                                                                       \
         "s_and_b32 %[cnt], s59, 0x7fffffff\n"  /* triangle count */ \
@@ -549,6 +553,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "v_cndmask_b32_e64 %[nx], %[nx], %[bb], %[MI]\n" \
         "L_next%=:\n" \
         "s_add_u32 %[noff], %[noff], 32\n" \
+        "L_test%=:\n" \
         "s_cmp_lt_u32 %[noff], %[nend]\n" \
         "s_cbranch_scc1 L_node%=\n" \
         "s_mov_b64 exec, %[EX]\n"                                                       
