@@ -114,10 +114,15 @@ __device__ __forceinline__ V3 ray_inverse_quick(V3 d) { return mk(recip_quick(d.
 // puts every divisor in recip_quick's range.  `normal`: also no component below 2^-126, so the
 // ray's own reciprocals are in range.  NaN components fail both.
 __device__ __forceinline__ void dir_class(V3 d, float bound, bool& small, bool& normal) {
-    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    small = ax < bound && ay < bound && az < bound;
-    const float tiny = 1.17549435e-38f;   // 2^-126
-    normal = small && ax >= tiny && ay >= tiny && az >= tiny;
+    small = fabsf(d.x) < bound && fabsf(d.y) < bound && fabsf(d.z) < bound;
+    const int kNormal = (1 << 3) | (1 << 8);   // v_cmp_class: negative / positive normal number
+    normal = small && __builtin_amdgcn_classf(d.x, kNormal) && __builtin_amdgcn_classf(d.y, kNormal) && __builtin_amdgcn_classf(d.z, kNormal);
+}
+
+// Finite (not infinite, not NaN) in one instruction per component.
+__device__ __forceinline__ bool finite3(V3 a) {
+    const int kFinite = 0x1F8;   // v_cmp_class: normal, denormal and zero of either sign
+    return __builtin_amdgcn_classf(a.x, kFinite) && __builtin_amdgcn_classf(a.y, kFinite) && __builtin_amdgcn_classf(a.z, kFinite);
 }
 
 // Triangle::intersect (orion/geometry.hpp:80-136).  Updates h on acceptance.
@@ -193,7 +198,7 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
     dir_class(d, S.dir_bound, d_small, d_normal);
     const bool quick_det = __all(d_small), quick_inv = __all(d_normal);   // wave-uniform choices of the arithmetic
     const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
-    const bool fast = __all(slab_safe(o, inv));
+    const bool fast = quick_inv ? __all(finite3(o)) : __all(slab_safe(o, inv));
     if (quick_det) traverse_lane_walk<ANY, true>(S, o, d, inv, fast, h);
     else traverse_lane_walk<ANY, false>(S, o, d, inv, fast, h);
 }
@@ -218,7 +223,8 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
     dir_class(d, S.dir_bound, d_small, d_normal);
     const bool quick_det = __all(!active || d_small), quick_inv = __all(!active || d_normal);   // wave-uniform
     const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
-    const bool fast = __all(!active || slab_safe(o, inv));   // wave-uniform choice of the slab arithmetic
+    // wave-uniform choice of the slab arithmetic; reciprocals of normal numbers below 2^126 are finite and not zero
+    const bool fast = quick_inv ? __all(!active || finite3(o)) : __all(!active || slab_safe(o, inv));
     uint32_t next = active ? 0u : kInvalid;
     const uint32_t n_nodes = S.n_nodes;
     if (!ANY) {   // the closest-hit walk is hand-scheduled; the loop below is the any-hit walk
