@@ -96,9 +96,11 @@ struct OrionScene {
         if (traversal == 1) return MODE_LANE;
         if (traversal == 2) return MODE_WAVE;
         if (traversal == 3) return MODE_EACH;
-        // The wave-synchronous walk costs the union of the lanes' paths, so it only
-        // pays while the whole tree is about as small as one ray's own path.
-        return n_nodes <= 64 ? MODE_WAVE : MODE_LANE;
+        // The wave-synchronous walk costs the union of the lanes' paths (subtrees no lane enters
+        // are jumped over), so it pays while that union stays near one ray's own path.  Measured
+        // on a 127-node scene: 2.3x the per-lane walk on rays towards surface points, +5 % on a
+        // point-light frame, -15 % on cosine bounce rays; at 38 k nodes the per-lane walk wins everywhere.
+        return n_nodes <= 128 ? MODE_WAVE : MODE_LANE;
     }
 };
 
