@@ -270,6 +270,8 @@ __device__ __forceinline__ void traverse_wave_loop(const SceneView& S, V3 o, V3 
             const bool in = fast ? slab_hit_fast(N.lo[0], N.lo[1], N.lo[2], N.hi[0], N.hi[1], N.hi[2], o, inv)
                                  : slab_hit(N.lo[0], N.lo[1], N.lo[2], N.hi[0], N.hi[1], N.hi[2], o, inv);
             if (!in) to = N.a;
+            // no lane enters: resume at the skip link (lanes get into a subtree through its root only)
+            if (__ballot(mine && in) == 0ull) node = N.a - 1u;
         }
         next = mine ? to : next;
     }
