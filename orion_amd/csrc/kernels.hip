@@ -98,9 +98,10 @@ struct OrionScene {
         if (traversal == 3) return MODE_EACH;
         // The wave-synchronous walk costs the union of the lanes' paths (subtrees no lane enters
         // are jumped over), so it pays while that union stays near one ray's own path.  Measured
-        // on a 127-node scene: 2.3x the per-lane walk on rays towards surface points, +5 % on a
-        // point-light frame, -15 % on cosine bounce rays; at 38 k nodes the per-lane walk wins everywhere.
-        return n_nodes <= 128 ? MODE_WAVE : MODE_LANE;
+        // on tessellated spheres (tools/ab/mode_threshold.py): for rays towards surface points it
+        // beats the per-lane walk up to about 500 nodes, for cosine bounce rays up to about 1000,
+        // for rays in pixel order at every size (those take it anyway, see orion_hip_render).
+        return n_nodes <= 512 ? MODE_WAVE : MODE_LANE;
     }
 };
 
@@ -678,13 +679,20 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((B.bound + tile - 1) / tile), dim3(kBlock), s->view, B.F, B.rad, B.qa,
                       prev, B.bound, B.qb, B.hits, cnt, clear, B.L->h_count + 2 * prev_slot, B.tags[prev_slot], n_bins);
         };
-        with_mode(mode, [&](auto M) {
+        // Rays of neighbouring pixels keep a wave together whatever the size of the tree, and the
+        // wave-synchronous walk costs the union of its lanes' paths: the primary rays, and the shadow
+        // rays a point-light frame casts from their hit points, take it in scenes of any size.
+        const bool coherent = depth == 0 && mode == MODE_LANE && s->traversal == 0;
+        with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
             if (depth == 0) {   // primary rays are generated inside the launch
                 if (wide) extend(k_extend<MODE, kRaysWide, true>); else extend(k_extend<MODE, 1, true>);
             } else {
                 if (wide) extend(k_extend<MODE, kRaysWide, false>); else extend(k_extend<MODE, 1, false>);
             }
+        });
+        with_mode(coherent && point ? (int)MODE_WAVE : mode, [&](auto M) {
+            constexpr int MODE = decltype(M)::value;
             auto shade = point ? k_shade<MODE, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf : k_shade<MODE, false>);
             launch_on(s, B.L->stream, ORION_KERNEL_SHADE, 0, shade, dim3(grid_for(B.bound)), dim3(kBlock), s->view, B.F, depth, B.qb, cnt, B.hits, B.qa, cnt + 1, B.rad);
         });

@@ -51,10 +51,7 @@ def hits_to_arrays(h):
 @pytest.mark.parametrize("name", SCENES)
 @pytest.mark.parametrize("mode,tag", MODES)
 def test_closest_hit_golden(gpu, name, mode, tag):
-    if tag == "wave" and name in ("nanosuit", "soup"):
-        batches = ["primary"]   # the wave-synchronous walk is not meant for big trees; one batch proves equality
-    else:
-        batches = BATCHES
+    batches = BATCHES   # every walk on every scene: big scenes take the wave-synchronous walk for their first bounce
     g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
     sc = scene_for(gpu, name)
     sc.set_option("traversal", mode)
@@ -70,8 +67,6 @@ def test_any_hit_golden(gpu, name):
     g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
     sc = scene_for(gpu, name)
     for mode, tag in MODES:
-        if tag == "wave" and name in ("nanosuit", "soup"):
-            continue
         sc.set_option("traversal", mode)
         for b in BATCHES:
             occ = sc.any_hit(g[f"{b}_org"], g[f"{b}_dir"])
