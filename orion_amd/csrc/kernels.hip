@@ -680,8 +680,9 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                       prev, B.bound, B.qb, B.hits, cnt, clear, B.L->h_count + 2 * prev_slot, B.tags[prev_slot], n_bins);
         };
         // Rays of neighbouring pixels keep a wave together whatever the size of the tree, and the
-        // wave-synchronous walk costs the union of its lanes' paths: the primary rays, and the shadow
-        // rays a point-light frame casts from their hit points, take it in scenes of any size.
+        // wave-synchronous walk costs the union of its lanes' paths: the primary rays take it in
+        // scenes of any size.  (The shadow rays a point-light frame casts from their hit points do
+        // not: measured on the 38 k-node nanosuit frame, the per-lane walk is 25 % faster on those.)
         const bool coherent = depth == 0 && mode == MODE_LANE && s->traversal == 0;
         with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
@@ -691,7 +692,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                 if (wide) extend(k_extend<MODE, kRaysWide, false>); else extend(k_extend<MODE, 1, false>);
             }
         });
-        with_mode(coherent && point ? (int)MODE_WAVE : mode, [&](auto M) {
+        with_mode(mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
             auto shade = point ? k_shade<MODE, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf : k_shade<MODE, false>);
             launch_on(s, B.L->stream, ORION_KERNEL_SHADE, 0, shade, dim3(grid_for(B.bound)), dim3(kBlock), s->view, B.F, depth, B.qb, cnt, B.hits, B.qa, cnt + 1, B.rad);
