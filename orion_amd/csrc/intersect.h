@@ -229,7 +229,7 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
     const uint32_t n_nodes = S.n_nodes;
     if (!ANY) {   // the closest-hit walk is hand-scheduled; the loop below is the any-hit walk
         const uint32_t ufast = __builtin_amdgcn_readfirstlane(fast ? 1u : 0u);
-        if (n_nodes) {
+        if (n_nodes && __any(active)) {   // (the walk relies on a lane being there to follow)
             if (quick_det) traverse_wave_closest_asm<true>(S, o, d, inv, h, next, ufast);
             else traverse_wave_closest_asm<false>(S, o, d, inv, h, next, ufast);
         }
@@ -392,9 +392,8 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "v_lshlrev_b32 %[nx], 5, %[nx]\n"  /* (kInvalid stays out of range) */ \
         "s_mov_b32 %[eps], 0x358637bd\n"  /* 1e-6f */ \
         "L_node%=:\n" \
+        /* the lanes at this node: never none -- the walk only moves to where the lane furthest behind waits */ \
         "v_cmp_eq_u32_e64 %[MI], %[noff], %[nx]\n" \
-        "s_cmp_eq_u64 %[MI], 0\n" \
-        "s_cbranch_scc1 L_next%=\n" \
         "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n"  /* lo.xyz a | hi.xyz b */ \
         "s_waitcnt lgkmcnt(0)\n" \
         "s_bitcmp1_b32 s59, 31\n"                                                                           \
