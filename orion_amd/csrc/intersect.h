@@ -214,10 +214,10 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
 // ---------------------------------------------------------------------------
 template <bool QUICK_DIV>
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast);
-template <bool ANY, bool QUICK>
-__device__ __forceinline__ void traverse_wave_loop(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, uint32_t next, HitRec& h);
-
-template <bool ANY>
+// Closest hit only.  A point-light shadow query ("is anything hit at t >= 0") is answered by the
+// same walk: a triangle is accepted against t = +inf under exactly the any-hit condition, and later
+// acceptances never undo a hit, so "h.gtri is set" means the same in both.  (A separate any-hit
+// loop that stopped at the first acceptance was 30 % slower than this walk run to its end.)
 __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
     bool d_small, d_normal;
     dir_class(d, S.dir_bound, d_small, d_normal);
@@ -225,55 +225,11 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
     const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
     // wave-uniform choice of the slab arithmetic; reciprocals of normal numbers below 2^126 are finite and not zero
     const bool fast = quick_inv ? __all(!active || finite3(o)) : __all(!active || slab_safe(o, inv));
-    uint32_t next = active ? 0u : kInvalid;
-    const uint32_t n_nodes = S.n_nodes;
-    if (!ANY) {   // the closest-hit walk is hand-scheduled; the loop below is the any-hit walk
-        const uint32_t ufast = __builtin_amdgcn_readfirstlane(fast ? 1u : 0u);
-        if (n_nodes && __any(active)) {   // (the walk relies on a lane being there to follow)
-            if (quick_det) traverse_wave_closest_asm<true>(S, o, d, inv, h, next, ufast);
-            else traverse_wave_closest_asm<false>(S, o, d, inv, h, next, ufast);
-        }
-        return;
-    }
-    if (quick_det) traverse_wave_loop<ANY, true>(S, o, d, inv, fast, next, h);
-    else traverse_wave_loop<ANY, false>(S, o, d, inv, fast, next, h);
-}
-
-template <bool ANY, bool QUICK>
-__device__ __forceinline__ void traverse_wave_loop(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, uint32_t next, HitRec& h) {
-    const uint32_t n_nodes = S.n_nodes;
-    for (uint32_t node = 0; node < n_nodes; node++) {
-        const uint32_t un = __builtin_amdgcn_readfirstlane(node);   // the walk is wave-uniform: keep it in SGPRs
-        const bool mine = (next == un);
-        if (__ballot(mine) == 0ull) {
-            if (ANY && !__any(next != kInvalid)) break;   // every lane has its answer
-            continue;
-        }
-        const Node N = S.nodes[un];
-        uint32_t to = un + 1;
-        if (N.b & kLeafFlag) {
-            const Tri* tp = S.tris + N.a;
-            const Tri* const te = tp + (N.b & ~kLeafFlag);
-            bool done = false;
-            for (; tp != te; tp++) {
-                const Tri T = *tp;
-                // The lanes that are not at this node sit the test out (execution mask), so its
-                // early exits fire as soon as the few lanes that are here have failed.
-                if (mine && !(ANY && done)) {
-                    bool acc = tri_hit<QUICK>(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.e1[0], T.e1[1], T.e1[2]),
-                                       mk(T.e2[0], T.e2[1], T.e2[2]), T.gtri, o, d, h);
-                    if (ANY && acc) done = true;
-                }
-            }
-            if (ANY && done) to = kInvalid;
-        } else {
-            const bool in = fast ? slab_hit_fast(N.lo[0], N.lo[1], N.lo[2], N.hi[0], N.hi[1], N.hi[2], o, inv)
-                                 : slab_hit(N.lo[0], N.lo[1], N.lo[2], N.hi[0], N.hi[1], N.hi[2], o, inv);
-            if (!in) to = N.a;
-            // no lane enters: resume at the skip link (lanes get into a subtree through its root only)
-            if (__ballot(mine && in) == 0ull) node = N.a - 1u;
-        }
-        next = mine ? to : next;
+    const uint32_t next = active ? 0u : kInvalid;
+    const uint32_t ufast = __builtin_amdgcn_readfirstlane(fast ? 1u : 0u);
+    if (S.n_nodes && __any(active)) {   // (the walk relies on a lane being there to follow)
+        if (quick_det) traverse_wave_closest_asm<true>(S, o, d, inv, h, next, ufast);
+        else traverse_wave_closest_asm<false>(S, o, d, inv, h, next, ufast);
     }
 }
 
@@ -371,8 +327,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 }
 
 // ---------------------------------------------------------------------------
-// The closest-hit wave walk, hand-scheduled.  The algorithm of traverse_wave
-// and the FP32 operations of slab_hit / slab_hit_fast and tri_hit in the same
+// The wave-synchronous walk, hand-scheduled.  The FP32 operations of slab_hit / slab_hit_fast and tri_hit in the same
 // order (the division is the compiler's own correctly rounded sequence, or recip_quick where
 // QUICK_DIV says the wave's rays allow it), but
 // with what the compiler will not do for this loop: one scalar pointer that

@@ -32,7 +32,7 @@ enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3 };
 template <int MODE, bool ANY>
 __device__ __forceinline__ void traverse(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
     if (MODE == MODE_WAVE) {
-        traverse_wave<ANY>(S, o, d, h, active);
+        traverse_wave(S, o, d, h, active);   // (answers any-hit queries too, see there)
     } else if (MODE == MODE_EACH) {
         traverse_one_each<ANY>(S, o, d, h, active);
     } else if (MODE == MODE_SAME) {
