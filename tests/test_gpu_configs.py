@@ -70,6 +70,24 @@ def test_c3_nanosuit_reduced(strategy, tag):
     compare(fr, 240, 135, 4, 1, model=model, strategy=strategy)
 
 
+def test_big_scene_walk_choice_changes_nothing():
+    """Scenes above the wave-synchronous limit trace their primary rays with that walk and the rest
+    per lane; forcing either walk for everything must give the same accumulator bit for bit."""
+    from orion_amd import api
+    fr = frame("c3_nanosuit_fhd")
+    W, H = 320, 180
+    cam = api.camera_vectors(fr.rtc.view_point, fr.rtc.look_at, fr.rtc.vector_up, fr.rtc.y_view, W / H)
+    sc = api.Scene(fr.model, device=0)
+    imgs = []
+    for traversal in (0, 1, 2):
+        sc.set_option("traversal", traversal)
+        imgs.append(sc.render(cam, W, H, 0, 4, 1, 3, seed=4, lights=fr.rtc.lights).copy())
+    sc.close()
+    assert imgs[0][:, :, :3].max() > 0
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[2].view(np.uint32))
+
+
 def test_c4_hindu_tiles_and_sample_shards():
     from orion_amd import api, dist as odist
     fr = frame("c4_hindu_4k")
