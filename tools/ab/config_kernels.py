@@ -1,8 +1,15 @@
-import os, sys, time
-sys.path.insert(0, '/root/repo')
-import torch
-from orion_amd import api
-ROOT='/root/repo'
+#!/usr/bin/env python3
+"""Per-kernel HIP-event times of the nanosuit and hindu config frames (one render call each)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+from orion_amd import api  # noqa: E402
+
 for name, ls, spp in (("c3_nanosuit_fhd",1,32),("c4_hindu_4k",1,16)):
     fr = api.load_frame(os.path.join(ROOT, "configs", name + ".rtc"), load_textures=False)
     W, H = fr.rtc.xres, fr.rtc.yres
