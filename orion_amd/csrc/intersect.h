@@ -166,28 +166,43 @@ __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]);
 // branch, the box), which turns one memory round trip per node into two dependent ones.
 __device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
+// Lanes that must stand at a leaf before the wave runs the triangle code (measured at 8, 16, 24,
+// 32 and 48 on three scenes: 16 is the best or within 3 % of it everywhere).
+constexpr int kLeafQuorum = 16;
+
 template <bool ANY, bool QUICK>
 __device__ __forceinline__ void traverse_lane_walk(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, HitRec& h) {
     uint32_t node = 0;
     const uint32_t n_nodes = S.n_nodes;
-    while (node < n_nodes) {
-        float4 A = reinterpret_cast<const float4*>(S.nodes)[2 * node];
-        float4 B = reinterpret_cast<const float4*>(S.nodes)[2 * node + 1];
-        pin(A); pin(B);   // both halves in one round trip (see pin)
-        const uint32_t a = __float_as_uint(A.w), b = __float_as_uint(B.w);
-        if (b & kLeafFlag) {
-            const uint32_t cnt = b & ~kLeafFlag;
+    uint32_t first = 0, cnt = 0;   // the leaf this lane is waiting to test (cnt == 0: none)
+    while (node < n_nodes || cnt) {
+        // Boxes first: every lane without a leaf moves along its skip links.  The triangle code
+        // runs once enough lanes stand at a leaf (or nobody is left to move) instead of in every
+        // turn for the one or two lanes that happen to be at a leaf, with the others waiting.
+        const bool moving = cnt == 0 && node < n_nodes;
+        if (moving) {
+            float4 A = reinterpret_cast<const float4*>(S.nodes)[2 * node];
+            float4 B = reinterpret_cast<const float4*>(S.nodes)[2 * node + 1];
+            pin(A); pin(B);   // both halves in one round trip (see pin)
+            const uint32_t a = __float_as_uint(A.w), b = __float_as_uint(B.w);
+            if (b & kLeafFlag) {
+                first = a; cnt = b & ~kLeafFlag;
+                node++;
+            } else {
+                const bool in = fast ? slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv) : slab_hit(A.x, A.y, A.z, B.x, B.y, B.z, o, inv);
+                node = in ? node + 1 : a;
+            }
+        }
+        const uint64_t waiting = __ballot(cnt != 0), going = __ballot(cnt == 0 && node < n_nodes);
+        if (__popcll(waiting) >= kLeafQuorum || going == 0ull) {
             for (uint32_t s = 0; s < cnt; s++) {
-                const float4* tp = reinterpret_cast<const float4*>(S.tris + (a + s));
+                const float4* tp = reinterpret_cast<const float4*>(S.tris + (first + s));
                 float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
                 pin(T0); pin(T1); pin(T2);
                 bool acc = tri_hit<QUICK>(mk(T0.x, T0.y, T0.z), mk(T1.x, T1.y, T1.z), mk(T2.x, T2.y, T2.z), __float_as_uint(T0.w), o, d, h);
                 if (ANY && acc) return;
             }
-            node++;
-        } else {
-            const bool in = fast ? slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv) : slab_hit(A.x, A.y, A.z, B.x, B.y, B.z, o, inv);
-            node = in ? node + 1 : a;
+            cnt = 0;
         }
     }
 }
