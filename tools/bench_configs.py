@@ -40,7 +40,7 @@ def main():
         st = sc.profile_read()
         rays = st["closest_hit"]["items"] + st["shadow"]["items"]
         n_ops = sum(len(m.nodes) for m in fr.model.meshes)
-        mode = {1: "per-lane", 2: "wave-synchronous"}.get(forced) or ("wave-synchronous" if n_ops <= 512 else "per-lane, primary rays wave-synchronous")
+        mode = {1: "per-lane", 2: "wave-synchronous"}.get(forced) or ("wave-synchronous" if n_ops <= 384 else "per-lane, primary rays wave-synchronous")
         print(f"| {name} | {W}x{H} | {fr.rtc.recursion_level} | {mode} | {spp} | {W * H * spp / dt / 1e6:.1f} | {rays / dt / 1e6:.1f} | "
               f"{W * H * spp_full / (W * H * spp / dt):.2f} s |", flush=True)
         sc.close()
