@@ -168,7 +168,9 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
 
 /* Tuning knobs, mainly for A/B measurements.  Known names:
  *   "traversal"   0 = choose per scene and per bounce (default: wave-synchronous for small
- *                 scenes and for the primary rays of any scene), 1 = per-lane traversal,
+ *                 scenes and for the primary rays of any scene; ray queries on large scenes decide
+ *                 per wave: rays leaving one point in nearly one direction walk together),
+ *                 1 = per-lane traversal,
  *                 2 = wave-synchronous traversal (scene data through scalar loads),
  *                 3 = one ray per wave at a time (scenes of at most 64 inner nodes +
  *                 triangles; slow on batches, it exists to test the walk the tail kernel uses)

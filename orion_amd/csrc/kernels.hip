@@ -103,6 +103,8 @@ struct OrionScene {
         // for rays in pixel order at every size (those take it anyway, see orion_hip_render).
         return n_nodes <= 384 ? MODE_WAVE : MODE_LANE;
     }
+    // Ray queries come in any order: on a large scene left to choose, each wave decides for itself.
+    int query_mode() const { return (traversal == 0 && mode() == MODE_LANE) ? (int)MODE_ADAPT : mode(); }
 };
 
 namespace {
@@ -245,8 +247,15 @@ void with_mode(int mode, F&& f) {
     }
 }
 
+// ... and for the ray-query kernels, which also come in the per-wave adaptive form.
+template <typename F>
+void with_query_mode(int mode, F&& f) {
+    if (mode == MODE_ADAPT) f(std::integral_constant<int, MODE_ADAPT>());
+    else with_mode(mode, f);
+}
+
 int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_out) {
-    with_mode(s->mode(), [&](auto M) {
+    with_query_mode(s->query_mode(), [&](auto M) {
         launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_closest_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     });
     HIP_TRY(hipGetLastError());
@@ -254,7 +263,7 @@ int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32
 }
 
 int launch_anyhit(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, uint8_t* d_out) {
-    with_mode(s->mode(), [&](auto M) {
+    with_query_mode(s->query_mode(), [&](auto M) {
         launch(s, ORION_KERNEL_ANY_HIT, n, k_anyhit_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     });
     HIP_TRY(hipGetLastError());

@@ -27,12 +27,31 @@ constexpr int kBlock = 256;
 // rays.  MODE_EACH: the wave takes its rays one at a time, all lanes on one ray (a way to run the
 // one-ray-per-wave walk on ordinary batches; its use is testing).  MODE_SAME: the caller guarantees
 // that all lanes hold the same ray and the same `active` (the tail kernel).
-enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3 };
+// MODE_ADAPT (ray queries on large scenes): each wave looks at its rays and takes the wave-synchronous
+// walk if they leave one point in nearly one direction (camera rays, rays towards a point light:
+// that walk costs the union of the lanes' paths, which such rays keep small), else the per-lane walk.
+enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4 };
+
+// True for every lane of a wave whose active rays share their origin exactly and lie within about
+// 25 degrees of the first active ray's direction.
+__device__ __forceinline__ bool wave_is_coherent(V3 o, V3 d, bool active) {
+    const uint64_t act = __ballot(active);
+    if (act == 0ull) return false;
+    const int first = __builtin_ctzll(act);
+    const V3 o0 = mk(__shfl(o.x, first), __shfl(o.y, first), __shfl(o.z, first));
+    const V3 d0 = mk(__shfl(d.x, first), __shfl(d.y, first), __shfl(d.z, first));
+    const float c = dot_raw(d, d0), n = dot_raw(d, d) * dot_raw(d0, d0);
+    const bool near = o.x == o0.x && o.y == o0.y && o.z == o0.z && c > 0.0f && c * c >= 0.82f * n;
+    return __all(!active || near);
+}
 
 template <int MODE, bool ANY>
 __device__ __forceinline__ void traverse(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
     if (MODE == MODE_WAVE) {
         traverse_wave(S, o, d, h, active);   // (answers any-hit queries too, see there)
+    } else if (MODE == MODE_ADAPT) {
+        if (wave_is_coherent(o, d, active)) traverse_wave(S, o, d, h, active);
+        else if (active) traverse_lane<ANY>(S, o, d, h);
     } else if (MODE == MODE_EACH) {
         traverse_one_each<ANY>(S, o, d, h, active);
     } else if (MODE == MODE_SAME) {

@@ -21,7 +21,7 @@ def main():
         jj, ii = np.meshgrid(np.arange(W), np.arange(H))
         jj, ii = jj.ravel(), ii.ravel()
         sc = api.Scene(fr.model, device=0)
-        sc.set_option("traversal", 2)
+        sc.set_option("traversal", int(os.environ.get("TRAVERSAL", "2")))
         line = f"{name:22s}"
         for tag, order in (("rows", np.arange(W * H)), ("8x8 blocks", np.lexsort((jj % 8, ii % 8, jj // 8, ii // 8))),
                            ("16x4 blocks", np.lexsort((jj % 16, ii % 4, jj // 16, ii // 4)))):
