@@ -304,6 +304,29 @@ def test_many_emissive_meshes_and_odd_light_samples(gpu):
     sc.close()
 
 
+@pytest.mark.parametrize("name", ["nanosuit", "soup"])
+def test_ray_queries_pick_their_walk_per_wave(gpu, name):
+    """On large scenes a wave of rays that leave one point in nearly one direction takes the
+    wave-synchronous walk, any other wave the per-lane one; a batch that mixes both kinds (and
+    waves that straddle them) must match the oracle bit for bit, any-hit answers included."""
+    model = conftest.load_model(name)
+    sc = scene_for(gpu, name)
+    orc = oracle_for(name)
+    n = 1 << 17
+    o, d = raygen.box_rays(model, n, seed=91)
+    rng = np.random.default_rng(92)
+    for start in range(0, n, 4096):            # every other 2048-ray stretch: a fan from one point, ragged ends
+        a, b = start + 37, start + 2048 + 11
+        o[a:b] = o[a]
+        d[a:b] = d[a] + (rng.random((b - a, 3)).astype(np.float32) - 0.5) * 0.15 * np.abs(d[a]).max()
+    sc.set_option("traversal", 0)
+    ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+    oid, otuv = orc.closest_hit(o, d, threads=8)
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(bits(tuv), bits(otuv))
+    assert np.array_equal(sc.any_hit(o, d).astype(bool), oid[:, 0] != gpu.INVALID)
+
+
 def test_the_three_walks_agree(gpu):
     """Per-lane, wave-synchronous (hand-scheduled assembly) and one-ray-per-wave traversal: same rays
     in, the same bits out -- ray queries, including waves pushed onto the exact-select slab test by
