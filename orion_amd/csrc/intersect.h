@@ -166,43 +166,48 @@ __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]);
 // branch, the box), which turns one memory round trip per node into two dependent ones.
 __device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
-// Lanes that must stand at a leaf before the wave runs the triangle code (measured at 8, 16, 24,
-// 32 and 48 on three scenes: 16 is the best or within 3 % of it everywhere).
+// Lanes that must hold two untested leaves before the wave runs the triangle code (measured at 8,
+// 16 and 32 on two large scenes: 16 is the best or within 3 % of it).
 constexpr int kLeafQuorum = 16;
 
 template <bool ANY, bool QUICK>
 __device__ __forceinline__ void traverse_lane_walk(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, HitRec& h) {
     uint32_t node = 0;
     const uint32_t n_nodes = S.n_nodes;
-    uint32_t first = 0, cnt = 0;   // the leaf this lane is waiting to test (cnt == 0: none)
-    while (node < n_nodes || cnt) {
-        // Boxes first: every lane without a leaf moves along its skip links.  The triangle code
-        // runs once enough lanes stand at a leaf (or nobody is left to move) instead of in every
-        // turn for the one or two lanes that happen to be at a leaf, with the others waiting.
-        const bool moving = cnt == 0 && node < n_nodes;
+    uint32_t first0 = 0, cnt0 = 0, first1 = 0, cnt1 = 0;   // up to two leaves this lane has yet to test, in visit order
+    while (node < n_nodes || cnt0) {
+        // Boxes first: a lane moves along its skip links and parks the leaves it reaches (the box
+        // tests do not depend on any triangle's result: the reference culls nothing by distance).
+        // The triangle code runs once enough lanes are full (or nobody is left to move) instead of
+        // in every turn for the one or two lanes that happen to be at a leaf, with the others waiting.
+        const bool moving = cnt1 == 0 && node < n_nodes;
         if (moving) {
             float4 A = reinterpret_cast<const float4*>(S.nodes)[2 * node];
             float4 B = reinterpret_cast<const float4*>(S.nodes)[2 * node + 1];
             pin(A); pin(B);   // both halves in one round trip (see pin)
             const uint32_t a = __float_as_uint(A.w), b = __float_as_uint(B.w);
             if (b & kLeafFlag) {
-                first = a; cnt = b & ~kLeafFlag;
+                const uint32_t c = b & ~kLeafFlag;
+                if (cnt0 == 0) { first0 = a; cnt0 = c; } else { first1 = a; cnt1 = c; }
                 node++;
             } else {
                 const bool in = fast ? slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv) : slab_hit(A.x, A.y, A.z, B.x, B.y, B.z, o, inv);
                 node = in ? node + 1 : a;
             }
         }
-        const uint64_t waiting = __ballot(cnt != 0), going = __ballot(cnt == 0 && node < n_nodes);
-        if (__popcll(waiting) >= kLeafQuorum || going == 0ull) {
-            for (uint32_t s = 0; s < cnt; s++) {
-                const float4* tp = reinterpret_cast<const float4*>(S.tris + (first + s));
-                float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
-                pin(T0); pin(T1); pin(T2);
-                bool acc = tri_hit<QUICK>(mk(T0.x, T0.y, T0.z), mk(T1.x, T1.y, T1.z), mk(T2.x, T2.y, T2.z), __float_as_uint(T0.w), o, d, h);
-                if (ANY && acc) return;
+        const uint64_t full = __ballot(cnt1 != 0), going = __ballot(cnt1 == 0 && node < n_nodes);
+        if (__popcll(full) >= kLeafQuorum || going == 0ull) {
+            for (int k = 0; k < 2; k++) {
+                const uint32_t first = k ? first1 : first0, cnt = k ? cnt1 : cnt0;
+                for (uint32_t s = 0; s < cnt; s++) {
+                    const float4* tp = reinterpret_cast<const float4*>(S.tris + (first + s));
+                    float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+                    pin(T0); pin(T1); pin(T2);
+                    bool acc = tri_hit<QUICK>(mk(T0.x, T0.y, T0.z), mk(T1.x, T1.y, T1.z), mk(T2.x, T2.y, T2.z), __float_as_uint(T0.w), o, d, h);
+                    if (ANY && acc) return;
+                }
             }
-            cnt = 0;
+            cnt0 = 0; cnt1 = 0;
         }
     }
 }
