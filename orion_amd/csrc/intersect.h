@@ -166,21 +166,21 @@ __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]);
 // branch, the box), which turns one memory round trip per node into two dependent ones.
 __device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
-// Lanes that must hold two untested leaves before the wave runs the triangle code (measured at 8,
-// 16 and 32 on two large scenes: 16 is the best or within 3 % of it).
-constexpr int kLeafQuorum = 16;
+// A lane parks up to kLeafSlots leaves; the wave runs the triangle code once kLeafQuorum lanes are
+// full.  Measured on two large scenes: slots 1 / 2 / 4 / 6 / 8 give 1 / 1.12 / 1.20 / 1.25 / 1.26 of
+// the one-slot rate on bounce rays; quorum 8, 16, 32 are within 3 % of each other.
+constexpr int kLeafSlots = 6, kLeafQuorum = 16;
 
 template <bool ANY, bool QUICK>
 __device__ __forceinline__ void traverse_lane_walk(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, HitRec& h) {
     uint32_t node = 0;
     const uint32_t n_nodes = S.n_nodes;
-    uint32_t first0 = 0, cnt0 = 0, first1 = 0, cnt1 = 0;   // up to two leaves this lane has yet to test, in visit order
-    while (node < n_nodes || cnt0) {
-        // Boxes first: a lane moves along its skip links and parks the leaves it reaches (the box
-        // tests do not depend on any triangle's result: the reference culls nothing by distance).
-        // The triangle code runs once enough lanes are full (or nobody is left to move) instead of
-        // in every turn for the one or two lanes that happen to be at a leaf, with the others waiting.
-        const bool moving = cnt1 == 0 && node < n_nodes;
+    constexpr int K = kLeafSlots;
+    uint32_t first[K], cnt[K];   // the leaves this lane has yet to test, in visit order (registers: every index below is a constant)
+#pragma unroll
+    for (int k = 0; k < K; k++) { first[k] = 0; cnt[k] = 0; }
+    while (node < n_nodes || cnt[0]) {
+        const bool moving = cnt[K - 1] == 0 && node < n_nodes;
         if (moving) {
             float4 A = reinterpret_cast<const float4*>(S.nodes)[2 * node];
             float4 B = reinterpret_cast<const float4*>(S.nodes)[2 * node + 1];
@@ -188,26 +188,33 @@ __device__ __forceinline__ void traverse_lane_walk(const SceneView& S, V3 o, V3 
             const uint32_t a = __float_as_uint(A.w), b = __float_as_uint(B.w);
             if (b & kLeafFlag) {
                 const uint32_t c = b & ~kLeafFlag;
-                if (cnt0 == 0) { first0 = a; cnt0 = c; } else { first1 = a; cnt1 = c; }
+                bool placed = false;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const bool here = !placed && cnt[k] == 0;
+                    first[k] = here ? a : first[k];
+                    cnt[k] = here ? c : cnt[k];
+                    placed = placed || here;
+                }
                 node++;
             } else {
                 const bool in = fast ? slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv) : slab_hit(A.x, A.y, A.z, B.x, B.y, B.z, o, inv);
                 node = in ? node + 1 : a;
             }
         }
-        const uint64_t full = __ballot(cnt1 != 0), going = __ballot(cnt1 == 0 && node < n_nodes);
+        const uint64_t full = __ballot(cnt[K - 1] != 0), going = __ballot(cnt[K - 1] == 0 && node < n_nodes);
         if (__popcll(full) >= kLeafQuorum || going == 0ull) {
-            for (int k = 0; k < 2; k++) {
-                const uint32_t first = k ? first1 : first0, cnt = k ? cnt1 : cnt0;
-                for (uint32_t s = 0; s < cnt; s++) {
-                    const float4* tp = reinterpret_cast<const float4*>(S.tris + (first + s));
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                for (uint32_t s = 0; s < cnt[k]; s++) {
+                    const float4* tp = reinterpret_cast<const float4*>(S.tris + (first[k] + s));
                     float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
                     pin(T0); pin(T1); pin(T2);
                     bool acc = tri_hit<QUICK>(mk(T0.x, T0.y, T0.z), mk(T1.x, T1.y, T1.z), mk(T2.x, T2.y, T2.z), __float_as_uint(T0.w), o, d, h);
                     if (ANY && acc) return;
                 }
+                cnt[k] = 0;
             }
-            cnt0 = 0; cnt1 = 0;
         }
     }
 }
