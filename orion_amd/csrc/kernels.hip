@@ -99,7 +99,7 @@ struct OrionScene {
         // The wave-synchronous walk costs the union of the lanes' paths (subtrees no lane enters
         // are jumped over), so it pays while that union stays near one ray's own path.  Measured
         // on tessellated spheres (tools/ab/mode_threshold.py): for rays towards surface points it
-        // beats the per-lane walk up to about 400 nodes, for cosine bounce rays up to about 500,
+        // beats the per-lane walk up to about 350 nodes, for cosine bounce rays up to about 400,
         // for rays in pixel order at every size (those take it anyway, see orion_hip_render).
         return n_nodes <= 384 ? MODE_WAVE : MODE_LANE;
     }
