@@ -67,6 +67,11 @@ def oracle_lib():
         L.oracle_camera_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int]
         L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_RenderParams), C.c_void_p, C.c_void_p]
         L.oracle_max_threads.restype = C.c_int
+        L.wide_model_create.restype = C.c_void_p
+        L.wide_model_create.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p]
+        L.wide_model_destroy.argtypes = [C.c_void_p]
+        L.wide_model_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wide_model_closest_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _oracle = L
     return _oracle
 
@@ -190,6 +195,40 @@ class OracleScene:
         counters = np.zeros(2, np.uint64)
         L.oracle_render(self.h, _p(cam), C.byref(p), _p(accum), _p(counters) if count else None)
         return (accum, counters) if count else accum
+
+
+class WideModel:
+    """CPU model of the product's wide-tree walk over a ``host.Model`` (trees from the product's host builder)."""
+
+    STATS = ["nodes", "own_fail", "leaves", "tris", "stale", "candidates", "max_stack", "max_excess_pads", "not_taken"]
+    NOT_TAKEN = 0xFFFFFFFE
+
+    def __init__(self, model):
+        from orion_amd import api
+        L = oracle_lib()
+        descs, self._keep = api.mesh_descs(model)
+        why = C.create_string_buffer(256)
+        self.h = L.wide_model_create(C.byref(descs), len(model.meshes), why)
+        self.why_not = why.value.decode()
+        if self.h:
+            info = np.zeros(2, np.uint32); finfo = np.zeros(2, np.float32)
+            L.wide_model_info(self.h, _p(info), _p(finfo))
+            self.n_nodes, self.stack_need = int(info[0]), int(info[1])
+            self.pad, self.org_bound = float(finfo[0]), float(finfo[1])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            oracle_lib().wide_model_destroy(self.h)
+            self.h = None
+
+    def closest_hit(self, org, dir, cull=True, threads=1, kappa=0.0):
+        o, d = _rays(org, dir)
+        n = len(o)
+        ids = np.zeros((n, 2), np.uint32); tuv = np.zeros((n, 3), np.float32); st = np.zeros(105, np.float64)
+        oracle_lib().wide_model_closest_hit(self.h, _p(o), _p(d), n, 1 if cull else 0, kappa, _p(ids), _p(tuv), _p(st), threads)
+        out = dict(zip(self.STATS, st[:9].tolist()))
+        out["depth_hist"] = st[9:41].copy(); out["steps_hist"] = st[41:105].copy()
+        return ids, tuv, out
 
 
 def normalize(xyz, rsqrt_mode=0):

@@ -130,6 +130,21 @@ def _settle(*tensors) -> None:
             return
 
 
+def mesh_descs(model: host.Model):
+    """The OrionMeshDesc array of a model and the arrays it points into (keep them alive)."""
+    keep: List[np.ndarray] = []
+    meshes = (_Mesh * max(1, len(model.meshes)))()
+    for i, m in enumerate(model.meshes):
+        v = np.ascontiguousarray(m.vertices, np.float32); ix = np.ascontiguousarray(m.indices, np.uint32)
+        nd = np.ascontiguousarray(m.nodes); to = np.ascontiguousarray(m.tri_order, np.uint32)
+        assert nd.dtype == host.NODE_DTYPE
+        keep += [v, ix, nd, to]
+        d = meshes[i]
+        d.vertices, d.n_vertices, d.indices, d.n_indices = v.ctypes.data, len(v), ix.ctypes.data, len(ix)
+        d.nodes, d.n_nodes, d.tri_order, d.material = nd.ctypes.data, len(nd), to.ctypes.data, m.material
+    return meshes, keep
+
+
 class Scene:
     """A model flattened and resident in HBM (orion_hip_scene_create)."""
 
@@ -157,15 +172,8 @@ class Scene:
         textures = (_Texture * max(1, len(tex_descs)))()
         for i, (w, h, f, p) in enumerate(tex_descs):
             textures[i].width, textures[i].height, textures[i].format, textures[i].texels = w, h, f, p
-        meshes = (_Mesh * max(1, len(model.meshes)))()
-        for i, m in enumerate(model.meshes):
-            v = np.ascontiguousarray(m.vertices, np.float32); ix = np.ascontiguousarray(m.indices, np.uint32)
-            nd = np.ascontiguousarray(m.nodes); to = np.ascontiguousarray(m.tri_order, np.uint32)
-            assert nd.dtype == host.NODE_DTYPE
-            keep += [v, ix, nd, to]
-            d = meshes[i]
-            d.vertices, d.n_vertices, d.indices, d.n_indices = v.ctypes.data, len(v), ix.ctypes.data, len(ix)
-            d.nodes, d.n_nodes, d.tri_order, d.material = nd.ctypes.data, len(nd), to.ctypes.data, m.material
+        meshes, mesh_keep = mesh_descs(model)
+        keep += mesh_keep
         h = C.c_void_p()
         _check(L.orion_hip_scene_create(C.byref(meshes), len(model.meshes), C.byref(mat_descs), len(model.materials),
                                         C.byref(textures), len(tex_descs), device, C.byref(h)))

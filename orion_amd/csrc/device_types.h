@@ -64,6 +64,39 @@ struct WaveItem {
 };
 static_assert(sizeof(WaveItem) == 64, "WaveItem layout");
 
+// One node of the 4-wide tree the ordered, distance-culled walk of large scenes uses (64 bytes,
+// four 16-byte loads).  It is a collapse of the reference's binary trees that keeps the reference's
+// visit rule: a triangle counts iff every binary inner node above it passes AABB::intersect
+// (orion/avx/sbvh.cpp:36-83, orion/AABB.hpp:79-99).
+//   * `lo`/`hi` is the exact box of the binary inner node this wide node stands for; the walk
+//     tests it with the reference's arithmetic when it enters the node.  Boxes of the binary nodes
+//     collapsed between a wide node and its parent contain it, and the slab test is monotone in
+//     the box for rays without NaN products, so they need no test of their own.
+//   * A leaf is only ever a slot of the wide node that stands for its binary parent (an inner node
+//     with a leaf child is never collapsed away): entering that wide node is the leaf's condition.
+//   * The four slots carry their boxes as bytes on a grid spanned by the node's own box grown by
+//     the scene's pad on every side (decoded: byte * cell + origin); a decoded box contains the
+//     slot's real box grown by the pad.  These boxes only ever REJECT: a slot is skipped when the
+//     ray misses its decoded box or meets it beyond the best hit so far.
+//   * ref: kWideEmpty, the index of a wide node, or kWideLeaf | count << 25 | first triangle slot.
+// Virtual nodes tie the meshes' roots together; their box is the union of what hangs below, grown
+// by more than any slack the walk applies, so that missing it means missing everything below.
+struct WideNode {
+    float lo[3]; uint32_t ref0;
+    float hi[3]; uint32_t ref1;
+    uint32_t qlo[3];        // per axis: the four slots' lower bounds, one byte each (slot 0 in bits 0-7)
+    uint32_t qhi[3];
+    uint32_t ref2, ref3;
+};
+static_assert(sizeof(WideNode) == 64, "WideNode layout");
+constexpr uint32_t kWideEmpty = 0x7FFFFFFFu;   // also "nothing left to visit" in the walk
+constexpr uint32_t kWideLeaf = 0x80000000u;
+constexpr uint32_t kWideMaxLeaf = 63;
+// The walk grows every decoded box by this fraction of the ray origin's distance to the farthest
+// corner of the node's grid (wide_walk.h explains what the slack is for).
+constexpr float kWideSlack = 0x1p-7f;
+constexpr float kWideInvCells = 1.0f / 254.0f;   // the byte grid spans the padded box with 255 / 254 of its extent
+
 struct Texture {
     uint32_t offset;   // element offset into texels_f32 (floats) or texels_u8 (bytes)
     uint32_t width, height;
@@ -98,6 +131,11 @@ struct SceneView {
     // Rays whose direction components are all below this in magnitude cannot produce a triangle
     // determinant of 2^126 or more in this scene (0 if the scene has non-finite edges).
     float dir_bound;
+    // The 4-wide tree of the ordered, distance-culled walk (n_wide == 0: the scene has none).
+    const WideNode* wide;
+    uint32_t n_wide;
+    float wide_pad;          // every decoded slot box contains its real box grown by this
+    float wide_org_bound;    // rays with an origin component beyond this take the unculled walk
 };
 
 // Closest-hit record kept in the queues: 16 bytes.  gtri == kInvalid is a miss.

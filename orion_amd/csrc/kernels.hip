@@ -14,6 +14,7 @@
 
 #include "../../include/orion_hip.h"
 #include "pathtrace.h"
+#include "wide_bvh.h"
 
 // ===========================================================================
 // Host side
@@ -77,7 +78,8 @@ struct OrionScene {
     std::vector<uint32_t> mesh_tri_base;
     uint32_t n_nodes = 0, n_tris = 0;
     // options
-    int traversal = 0;                // 0 auto, 1 lane, 2 wave, 3 one ray per wave at a time
+    int traversal = 0;                // 0 auto, 1 lane, 2 wave, 3 one ray per wave at a time, 4 wide tree
+    std::string wide_why_not;         // why the scene has no wide tree ("" if it has one)
     uint32_t tail_paths = 1u << 16;   // hand a batch's last paths to k_tail once this few are left
     uint64_t batch_paths = 64u << 20;     // paths in flight per batch (128 B of queues each)
     uint32_t overlap_below = 4u << 20;    // start the next batch on the other lane once this few rays are left (0: never)
@@ -96,15 +98,22 @@ struct OrionScene {
         if (traversal == 1) return MODE_LANE;
         if (traversal == 2) return MODE_WAVE;
         if (traversal == 3) return MODE_EACH;
+        if (traversal == 4) return MODE_WIDE;
         // The wave-synchronous walk costs the union of the lanes' paths (subtrees no lane enters
         // are jumped over), so it pays while that union stays near one ray's own path.  Measured
         // on tessellated spheres (tools/ab/mode_threshold.py): for rays towards surface points it
         // beats the per-lane walk up to about 350 nodes, for cosine bounce rays up to about 400,
         // for rays in pixel order at every size (those take it anyway, see orion_hip_render).
-        return n_nodes <= 384 ? MODE_WAVE : MODE_LANE;
+        // Larger scenes: the ordered, distance-culled walk of the 4-wide tree where the scene has one.
+        if (n_nodes <= 384) return MODE_WAVE;
+        return view.n_wide ? MODE_WIDE : MODE_LANE;
     }
+    bool per_lane() const { const int m = mode(); return m == MODE_LANE || m == MODE_WIDE; }
     // Ray queries come in any order: on a large scene left to choose, each wave decides for itself.
-    int query_mode() const { return (traversal == 0 && mode() == MODE_LANE) ? (int)MODE_ADAPT : mode(); }
+    int query_mode() const {
+        if (traversal != 0 || !per_lane()) return mode();
+        return mode() == MODE_WIDE ? (int)MODE_ADAPT_WIDE : (int)MODE_ADAPT;
+    }
 };
 
 namespace {
@@ -243,6 +252,7 @@ void with_mode(int mode, F&& f) {
     switch (mode) {
         case MODE_WAVE: f(std::integral_constant<int, MODE_WAVE>()); break;
         case MODE_EACH: f(std::integral_constant<int, MODE_EACH>()); break;
+        case MODE_WIDE: f(std::integral_constant<int, MODE_WIDE>()); break;
         default: f(std::integral_constant<int, MODE_LANE>()); break;
     }
 }
@@ -251,10 +261,19 @@ void with_mode(int mode, F&& f) {
 template <typename F>
 void with_query_mode(int mode, F&& f) {
     if (mode == MODE_ADAPT) f(std::integral_constant<int, MODE_ADAPT>());
+    else if (mode == MODE_ADAPT_WIDE) f(std::integral_constant<int, MODE_ADAPT_WIDE>());
     else with_mode(mode, f);
 }
 
 int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_out) {
+    const int qm = s->query_mode();
+    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) {
+        const dim3 grid((n + kQueryTile - 1) / kQueryTile);
+        if (qm == MODE_WIDE) launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_query_wide<false, false>, grid, dim3(kBlock), s->view, d_org, d_dir, n, d_out, (uint8_t*)nullptr);
+        else launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_query_wide<false, true>, grid, dim3(kBlock), s->view, d_org, d_dir, n, d_out, (uint8_t*)nullptr);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     with_query_mode(s->query_mode(), [&](auto M) {
         launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_closest_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     });
@@ -263,6 +282,14 @@ int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32
 }
 
 int launch_anyhit(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, uint8_t* d_out) {
+    const int qm = s->query_mode();
+    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) {
+        const dim3 grid((n + kQueryTile - 1) / kQueryTile);
+        if (qm == MODE_WIDE) launch(s, ORION_KERNEL_ANY_HIT, n, k_query_wide<true, false>, grid, dim3(kBlock), s->view, d_org, d_dir, n, (OrionHit*)nullptr, d_out);
+        else launch(s, ORION_KERNEL_ANY_HIT, n, k_query_wide<true, true>, grid, dim3(kBlock), s->view, d_org, d_dir, n, (OrionHit*)nullptr, d_out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     with_query_mode(s->query_mode(), [&](auto M) {
         launch(s, ORION_KERNEL_ANY_HIT, n, k_anyhit_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     });
@@ -334,6 +361,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     }
 
     uint32_t tri_base = 0;
+    std::vector<uint32_t> slot_bases;
     for (uint32_t mi = 0; mi < n_meshes; mi++) {
         const OrionMeshDesc& m = meshes[mi];
         const std::string where = "scene_create: mesh " + std::to_string(mi) + ": ";
@@ -351,6 +379,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         }
 
         const uint32_t slot_base = (uint32_t)tris.size();
+        slot_bases.push_back(slot_base);
         if (m.n_nodes) {
             Flattener fl{m, slot_base, nodes, std::vector<uint8_t>(m.n_nodes, 0), std::string()};
             if (!fl.emit(0)) return fail(1, where + fl.err);
@@ -431,6 +460,12 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         }
     }
 
+    // The 4-wide tree of the ordered, distance-culled walk: for scenes too large for the wave-synchronous
+    // walk, where the trees allow it (wide_bvh.h) and the walk's stack is deep enough for most paths.
+    orion_wide::WideTree wide;
+    if (nodes.size() > 64) wide = orion_wide::build_wide_tree(meshes, n_meshes, slot_bases, tris);
+    else wide.why_not = "the scene is small";
+
     std::vector<Texture> dtex(n_textures);
     std::vector<float> texf;
     std::vector<uint8_t> texb;
@@ -480,6 +515,11 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     v.n_nodes = (uint32_t)nodes.size(); v.n_tris = (uint32_t)tris.size();
     v.n_meshes = n_meshes; v.n_emissive = (uint32_t)emissive.size();
     if (!items.empty()) { if ((rc = upload(s, items, &v.items))) return bail(rc); v.n_items = 64; }
+    if (!wide.nodes.empty()) {
+        if ((rc = upload(s, wide.nodes, &v.wide))) return bail(rc);
+        v.n_wide = (uint32_t)wide.nodes.size(); v.wide_pad = wide.pad; v.wide_org_bound = wide.org_bound;
+    }
+    s->wide_why_not = wide.why_not;
     {   // |det| = |e1 . (d x e2)| <= 6 D E^2 for direction components up to D and edge components up to E;
         // D < 2^122 / E^2 keeps it (and every intermediate, rounding included) below 2^126 with room to spare
         double E = 0.0;
@@ -522,7 +562,8 @@ int orion_hip_scene_destroy(OrionScene* s) {
 int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
     if (!s || !name) return fail(1, "set_option: null argument");
     if (!std::strcmp(name, "traversal")) {
-        if (value < 0 || value > 3) return fail(1, "set_option: traversal must be 0, 1, 2 or 3");
+        if (value < 0 || value > 4) return fail(1, "set_option: traversal must be 0, 1, 2, 3 or 4");
+        if (value == 4 && s->view.n_wide == 0) return fail(1, "set_option: the scene has no wide tree (" + s->wide_why_not + ")");
         if (value == 3 && s->view.n_items == 0) return fail(1, "set_option: the scene is too large for one ray per wave (more than 64 inner nodes + triangles)");
         s->traversal = (int)value;
         return 0;
@@ -628,9 +669,10 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         HIP_TRY(hipStreamWaitEvent(s->lane[1].stream, s->ev_upload, 0));
     }
     const int mode = s->mode();
-    const bool tail_ok = s->view.n_items != 0 && mode != MODE_LANE && s->tail_paths != 0;
+    const bool per_lane = s->per_lane();
+    const bool tail_ok = s->view.n_items != 0 && !per_lane && s->tail_paths != 0;
     const uint64_t rays_per_vertex = point ? p->n_lights : (uint64_t)p->light_samples * s->view.n_emissive;
-    const uint32_t n_bins = (mode != MODE_LANE) ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
+    const uint32_t n_bins = !per_lane ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
     const uint64_t n_batches = (p->spp_end - p->spp_begin + per_batch - 1) / per_batch;
     const bool two_lanes = n_batches > 1 && s->overlap_below != 0;
 
@@ -692,7 +734,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         // wave-synchronous walk costs the union of its lanes' paths: the primary rays take it in
         // scenes of any size.  (The shadow rays a point-light frame casts from their hit points do
         // not: measured on the 38 k-node nanosuit frame, the per-lane walk is 25 % faster on those.)
-        const bool coherent = depth == 0 && mode == MODE_LANE && s->traversal == 0;
+        const bool coherent = depth == 0 && per_lane && s->traversal == 0;
         with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
             if (depth == 0) {   // primary rays are generated inside the launch

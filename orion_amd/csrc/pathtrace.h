@@ -13,6 +13,7 @@
 #pragma once
 
 #include "shading.h"
+#include "wide_walk.h"
 
 using namespace orion_dev;
 
@@ -22,6 +23,7 @@ using namespace orion_dev;
 namespace {
 
 constexpr int kBlock = 256;
+static_assert(kBlock == kWideBlock, "the wide walk's stack is laid out for this block size");
 
 // MODE_LANE: every lane walks on its own.  MODE_WAVE: the wave walks the node array once for its 64
 // rays.  MODE_EACH: the wave takes its rays one at a time, all lanes on one ray (a way to run the
@@ -30,7 +32,9 @@ constexpr int kBlock = 256;
 // MODE_ADAPT (ray queries on large scenes): each wave looks at its rays and takes the wave-synchronous
 // walk if they leave one point in nearly one direction (camera rays, rays towards a point light:
 // that walk costs the union of the lanes' paths, which such rays keep small), else the per-lane walk.
-enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4 };
+// MODE_WIDE: every lane walks the 4-wide tree, nearest first, with distance culling (wide_walk.h);
+// MODE_ADAPT_WIDE: MODE_ADAPT with that walk for the waves that are not coherent.
+enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4, MODE_WIDE = 5, MODE_ADAPT_WIDE = 6 };
 
 // True for every lane of a wave whose active rays share their origin exactly and lie within about
 // 25 degrees of the first active ray's direction.
@@ -52,6 +56,11 @@ __device__ __forceinline__ void traverse(const SceneView& S, V3 o, V3 d, HitRec&
     } else if (MODE == MODE_ADAPT) {
         if (wave_is_coherent(o, d, active)) traverse_wave(S, o, d, h, active);
         else if (active) traverse_lane<ANY>(S, o, d, h);
+    } else if (MODE == MODE_ADAPT_WIDE) {
+        if (wave_is_coherent(o, d, active)) traverse_wave(S, o, d, h, active);
+        else if (active) traverse_wide<ANY>(S, o, d, h);
+    } else if (MODE == MODE_WIDE) {
+        if (active) traverse_wide<ANY>(S, o, d, h);
     } else if (MODE == MODE_EACH) {
         traverse_one_each<ANY>(S, o, d, h, active);
     } else if (MODE == MODE_SAME) {
@@ -125,6 +134,114 @@ __global__ __launch_bounds__(kBlock) void k_anyhit_api(SceneView S, const float*
     HitRec h = miss_rec();
     traverse<MODE, true>(S, o, d, h, active);
     if (active) out[i] = h.gtri != kInvalid ? 1 : 0;
+}
+
+// The ray queries of large scenes (MODE_WIDE, MODE_ADAPT_WIDE).  Incoherent rays take wildly different
+// numbers of steps through the tree (half of them a handful, one in a hundred over a hundred), and a wave
+// that holds 64 rays from start to end runs as long as its longest one with most lanes idle.  Here a block
+// owns a tile of kQueryTile rays and its lanes draw rays from it one at a time: whenever kRefillMin lanes
+// of a wave have finished theirs, they fetch new ones (one LDS atomic per wave and refill).
+// ADAPT: each wave first looks at the tile's 64-ray chunks in turn; a chunk whose rays leave one point in
+// nearly one direction (camera rays) goes through the wave-synchronous walk at once, the others join the
+// pool the lanes draw from.
+constexpr uint32_t kQueryRays = 8;                      // rays per thread of a tile
+constexpr uint32_t kQueryTile = kBlock * kQueryRays;
+constexpr uint32_t kRefillMin = 16;
+
+template <bool ANY>
+__device__ __forceinline__ void query_store(const SceneView& S, uint32_t i, const HitRec& h, OrionHit* __restrict__ out, uint8_t* __restrict__ occ) {
+    if (ANY) { occ[i] = h.gtri != kInvalid ? 1 : 0; return; }
+    OrionHit r;
+    r.mesh = kInvalid; r.tri = kInvalid; r.t = h.t; r.u = h.u; r.v = h.v;
+    if (h.gtri != kInvalid) {
+        r.mesh = S.attrs[h.gtri].mesh;
+        r.tri = h.gtri - S.meshes[r.mesh].tri_base;
+    }
+    out[i] = r;
+}
+
+template <bool ANY, bool ADAPT>
+__global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float* __restrict__ org, const float* __restrict__ dir,
+                                                       uint32_t n, OrionHit* __restrict__ out, uint8_t* __restrict__ occ) {
+    __shared__ uint32_t s_next, s_nlist;
+    __shared__ uint8_t s_list[kQueryTile / 64];
+    const uint32_t tile0 = blockIdx.x * kQueryTile;
+    const uint32_t tile_n = min(kQueryTile, n - tile0);
+    const uint32_t lane = lane_id(), tid = threadIdx.x;
+    if (tid == 0) { s_next = 0u; s_nlist = 0u; }
+    __syncthreads();
+    if (ADAPT) {
+        const uint32_t n_chunks = (tile_n + 63u) / 64u;
+        for (uint32_t chunk = tid >> 6; chunk < n_chunks; chunk += kBlock / 64) {
+            const uint32_t i = tile0 + chunk * 64u + lane;
+            const bool active = i < n;
+            V3 o = splat(0.0f), d = splat(1.0f);
+            if (active) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); }
+            if (wave_is_coherent(o, d, active)) {
+                HitRec h = miss_rec();
+                traverse_wave(S, o, d, h, active);
+                if (active) query_store<ANY>(S, i, h, out, occ);
+            } else if (lane == 0) {
+                s_list[atomicAdd(&s_nlist, 1u)] = (uint8_t)chunk;
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t pool = ADAPT ? s_nlist * 64u : tile_n;
+
+    uint32_t ray = kInvalid;
+    V3 o = splat(0.0f), d = splat(1.0f), inv = splat(1.0f);
+    HitRec h = miss_rec();
+    WideState w; w.cur = kWideEmpty; w.sp = 0u; w.best_slot = 0u;
+    bool quick_det = false, slow = false, exhausted = false;
+    for (;;) {
+        const bool idle = w.cur == kWideEmpty && !slow && !exhausted;
+        const uint64_t mi = __ballot(idle);
+        const uint64_t busy = __ballot(w.cur != kWideEmpty || slow);
+        if (mi != 0ull && ((uint32_t)__popcll(mi) >= kRefillMin || busy == 0ull)) {
+            const int leader = __builtin_ctzll(mi);
+            uint32_t base = 0u;
+            if ((int)lane == leader) base = atomicAdd(&s_next, (uint32_t)__popcll(mi));
+            base = __shfl(base, leader);
+            if (idle) {
+                const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+                if (idx < pool) {
+                    const uint32_t i = ADAPT ? tile0 + (uint32_t)s_list[idx >> 6] * 64u + (idx & 63u) : tile0 + idx;
+                    if (i < n) {
+                        o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i);
+                        bool d_small, d_normal;
+                        dir_class(d, S.dir_bound, d_small, d_normal);
+                        quick_det = d_small;
+                        inv = ray_inverse(d);
+                        h = miss_rec();
+                        ray = i;
+                        if (wide_tame(S, o, d)) { w.cur = 0u; w.sp = 0u; w.best_slot = 0u; }
+                        else slow = true;
+                    }
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (__ballot(w.cur != kWideEmpty || slow) == 0ull) {
+            if (__ballot(!exhausted) == 0ull) break;
+            continue;
+        }
+        // rays the wide walk does not take, and lanes whose stack overflowed: the unculled walk
+        if (__any(slow)) {
+            if (slow) { h = miss_rec(); traverse_lane<ANY>(S, o, d, h); slow = false; w.cur = kWideEmpty; }
+        }
+        while (wide_at_node(w)) {
+            if (!wide_node_step(S, o, inv, h.t, w, tid)) slow = true;
+        }
+        const bool at_leaf = wide_at_leaf(w);
+        const bool all_quick = __all(!at_leaf || quick_det);
+        if (at_leaf) {
+            if (all_quick) wide_leaf_step<ANY, true>(S, o, d, h, w, tid);
+            else wide_leaf_step<ANY, false>(S, o, d, h, w, tid);
+        }
+        if (ray != kInvalid && w.cur == kWideEmpty && !slow) { query_store<ANY>(S, ray, h, out, occ); ray = kInvalid; }
+    }
 }
 
 // --- path tracing --------------------------------------------------------------

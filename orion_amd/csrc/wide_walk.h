@@ -1,0 +1,178 @@
+// The walk of large scenes: every lane takes its ray through the 4-wide tree (WideNode,
+// device_types.h; built by wide_bvh.h) nearest slot first, skipping what cannot matter, and still
+// returns what the reference's unordered, unculled walk returns (orion/avx/sbvh.cpp:36-83,
+// orion/model.hpp:52-62), bit for bit:
+//
+//   * Visit rule.  The reference tests a triangle iff every binary inner node above it passes
+//     AABB::intersect.  A wide node carries the exact box of the binary inner node it stands for and the
+//     walk tests it on entry with the reference's arithmetic; the inner nodes collapsed away above it
+//     contain that box, and for a ray whose slab products cannot be NaN the test is monotone in the box,
+//     so they pass whenever it does.  Leaves hang from the wide node of their own binary parent.
+//   * Result rule.  The reference keeps a candidate unless t > best (orion/geometry.hpp:127), so it ends
+//     with the smallest t and, among equal t, the LAST triangle in its visit order.  Triangle slots are
+//     stored in that order (meshes in load order, each tree depth first), so in any visiting order
+//     "t < best, or t == best and slot > best slot" selects the same triangle with the same t, u, v.
+//   * Skipping.  A slot's decoded box contains the slot's real box grown by the scene's pad, and the walk
+//     grows it further by kWideSlack times the origin's distance to the farthest corner of the node's grid.  An inner slot
+//     missed by the ray would fail the reference's own test on the (smaller) real box.  Two more skips
+//     rest on one assumption, that the reference's computed hit point o + t*d of a triangle it accepts
+//     lies inside the triangle's box grown by that much: a leaf whose grown box the ray misses, and any
+//     slot whose grown box begins beyond the best hit so far.  The triangle test's rounding moves the
+//     computed hit by about 1e-5 / (sin(apex angle) * cos(angle to the normal)) of its distance, so the
+//     assumption can only fail for a ray within a fraction of a degree of the plane of a triangle that
+//     also lies behind the hit the ray does find; the CPU model of this walk and the unculled walk agree
+//     on every one of 10^8 rays aimed along and across two scenes' surfaces (tools/ab/stress_parity.py,
+//     tests/test_wide_tree.py).  Option "traversal" = 1 keeps the unculled per-lane walk.
+//   * Rays the argument does not cover -- an origin component that is not finite or beyond the scene's
+//     bound, a direction component that is zero, denormal, not finite or outside 2^-40 .. 2^40 -- and
+//     lanes whose stack would overflow take the unculled walk (traverse_lane) instead.
+#pragma once
+
+#include "intersect.h"
+
+namespace orion_dev {
+
+constexpr int kWideBlock = 256;    // threads per block of every kernel that walks the wide tree
+constexpr int kWideStack = 16;     // stack entries per lane (LDS: 8 bytes each)
+
+// One lane's stack entry: what to visit and where its grown box begins along the ray.
+// [depth][thread]: a lane's entries sit in the same banks at every depth.
+__shared__ uint2 g_wide_stack[kWideStack][kWideBlock];
+
+// (compiles to one v_cvt_f32_ubyteK)
+template <int K> __device__ __forceinline__ float byte_of(uint32_t w) { return (float)((w >> (8 * K)) & 0xFFu); }
+
+// What a lane is doing: `cur` is kWideEmpty (nothing left), a wide node's index, or a leaf reference.
+struct WideState { uint32_t cur, sp, best_slot; };
+
+__device__ __forceinline__ bool wide_at_node(const WideState& w) { return !(w.cur & kWideLeaf) && w.cur != kWideEmpty; }
+__device__ __forceinline__ bool wide_at_leaf(const WideState& w) { return (w.cur & kWideLeaf) != 0u; }
+
+// Next entry from the lane's stack; entries whose box begins beyond the best hit by now are dropped unvisited.
+__device__ __forceinline__ void wide_pop(WideState& w, float best, uint32_t tid) {
+    w.cur = kWideEmpty;
+    while (w.sp) {
+        w.sp--;
+        const uint2 e = g_wide_stack[w.sp][tid];
+        if (!(__uint_as_float(e.y) > best)) { w.cur = e.x; break; }
+    }
+}
+
+// Slot K's entry distance, or +inf if the slot is empty, missed, behind the origin or beyond `best`.
+// The slab distances come straight from the bytes: (byte * cell + origin -+ r - o) * inv, multiplied out
+// (c = cell * inv, l / u = (origin - o -+ r) * inv); its rounding is ten-thousandths of the slack r.
+template <int K>
+__device__ __forceinline__ float wide_slot(const float4& C, const float4& D, V3 c, V3 l, V3 u, float best, uint32_t ref) {
+    const float t1x = fmaf(byte_of<K>(__float_as_uint(C.x)), c.x, l.x), t2x = fmaf(byte_of<K>(__float_as_uint(C.w)), c.x, u.x);
+    const float t1y = fmaf(byte_of<K>(__float_as_uint(C.y)), c.y, l.y), t2y = fmaf(byte_of<K>(__float_as_uint(D.x)), c.y, u.y);
+    const float t1z = fmaf(byte_of<K>(__float_as_uint(C.z)), c.z, l.z), t2z = fmaf(byte_of<K>(__float_as_uint(D.y)), c.z, u.z);
+    const float tmin = vmax3(vmin(t1x, t2x), vmin(t1y, t2y), vmin(t1z, t2z));
+    const float tmax = vmin3(vmax(t1x, t2x), vmax(t1y, t2y), vmax(t1z, t2z));
+    const bool hit = ref != kWideEmpty && tmax >= tmin && tmax >= 0.0f && tmin <= best;
+    return hit ? tmin : __builtin_inff();
+}
+
+// One wide node: the reference's test on its own box, then the four slots; the nearest one is next and the
+// others go onto the stack.  Returns false if the stack would overflow (the lane then has to start over
+// with the unculled walk).
+__device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid) {
+    const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
+    float4 A = np[0], B = np[1], C = np[2], D = np[3];
+    pin(A); pin(B); pin(C); pin(D);
+    const float inf = __builtin_inff();
+    float t0 = inf, t1 = inf, t2 = inf, t3 = inf;
+    const uint32_t r0 = __float_as_uint(A.w), r1 = __float_as_uint(B.w), r2 = __float_as_uint(D.z), r3 = __float_as_uint(D.w);
+    if (slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv)) {
+        const float pad = S.wide_pad, pad2 = 2.0f * pad;
+        const V3 org = mk(A.x - pad, A.y - pad, A.z - pad);
+        const V3 cell = mk(((B.x - A.x) + pad2) * kWideInvCells, ((B.y - A.y) + pad2) * kWideInvCells, ((B.z - A.z) + pad2) * kWideInvCells);
+        const V3 n0 = org - o;                                                                          // near end of the grid, from the origin
+        const V3 n1 = mk(fmaf(255.0f, cell.x, org.x) - o.x, fmaf(255.0f, cell.y, org.y) - o.y, fmaf(255.0f, cell.z, org.z) - o.z);   // far end
+        const float reach = fmaxf(vmax3(fabsf(n0.x), fabsf(n1.x), fabsf(n0.y)), vmax3(fabsf(n1.y), fabsf(n0.z), fabsf(n1.z)));
+        const float r = kWideSlack * reach;
+        const V3 c = cell * inv;
+        const V3 l = mk((n0.x - r) * inv.x, (n0.y - r) * inv.y, (n0.z - r) * inv.z);
+        const V3 u = mk((n0.x + r) * inv.x, (n0.y + r) * inv.y, (n0.z + r) * inv.z);
+        t0 = wide_slot<0>(C, D, c, l, u, best, r0);
+        t1 = wide_slot<1>(C, D, c, l, u, best, r1);
+        t2 = wide_slot<2>(C, D, c, l, u, best, r2);
+        t3 = wide_slot<3>(C, D, c, l, u, best, r3);
+    }
+    const float tn = fminf(fminf(t0, t1), fminf(t2, t3));
+    if (!(tn < inf)) { wide_pop(w, best, tid); return true; }
+    const uint32_t kn = t0 == tn ? 0u : (t1 == tn ? 1u : (t2 == tn ? 2u : 3u));
+    const bool p0 = t0 < inf && kn != 0u, p1 = t1 < inf && kn != 1u, p2 = t2 < inf && kn != 2u, p3 = t3 < inf && kn != 3u;
+    if (w.sp + (p0 ? 1u : 0u) + (p1 ? 1u : 0u) + (p2 ? 1u : 0u) + (p3 ? 1u : 0u) > (uint32_t)kWideStack) { w.cur = kWideEmpty; return false; }
+    if (p3) { g_wide_stack[w.sp][tid] = make_uint2(r3, __float_as_uint(t3)); w.sp++; }
+    if (p2) { g_wide_stack[w.sp][tid] = make_uint2(r2, __float_as_uint(t2)); w.sp++; }
+    if (p1) { g_wide_stack[w.sp][tid] = make_uint2(r1, __float_as_uint(t1)); w.sp++; }
+    if (p0) { g_wide_stack[w.sp][tid] = make_uint2(r0, __float_as_uint(t0)); w.sp++; }
+    w.cur = kn == 0u ? r0 : (kn == 1u ? r1 : (kn == 2u ? r2 : r3));
+    return true;
+}
+
+// A leaf: its triangles in slot order, each against t = +inf (Triangle::intersect's candidate test), the
+// result rule of the header comment deciding between candidates.  Returns true when ANY is set and the ray
+// has a hit (the any-hit callers only ask whether there is one).
+template <bool ANY, bool QUICK>
+__device__ __forceinline__ bool wide_leaf_step(const SceneView& S, V3 o, V3 d, HitRec& h, WideState& w, uint32_t tid) {
+    const uint32_t first = w.cur & 0x01FFFFFFu, count = (w.cur >> 25) & 63u;
+    for (uint32_t s = 0; s < count; s++) {
+        const float4* tp = reinterpret_cast<const float4*>(S.tris + (first + s));
+        float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+        pin(T0); pin(T1); pin(T2);
+        HitRec c; c.t = __builtin_inff(); c.u = 0.0f; c.v = 0.0f; c.gtri = kInvalid;
+        if (tri_hit<QUICK>(mk(T0.x, T0.y, T0.z), mk(T1.x, T1.y, T1.z), mk(T2.x, T2.y, T2.z), __float_as_uint(T0.w), o, d, c)) {
+            if (c.t < h.t || (c.t == h.t && first + s > w.best_slot)) { h = c; w.best_slot = first + s; }
+            if (ANY) { w.cur = kWideEmpty; return true; }
+        }
+    }
+    wide_pop(w, h.t, tid);
+    return false;
+}
+
+// Which rays the wide walk takes (see the header comment).
+__device__ __forceinline__ bool wide_tame(const SceneView& S, V3 o, V3 d) {
+    const int kNormal = (1 << 3) | (1 << 8);
+    const float ob = S.wide_org_bound;
+    const bool o_ok = fabsf(o.x) <= ob && fabsf(o.y) <= ob && fabsf(o.z) <= ob;   // false for NaN
+    const bool d_ok = __builtin_amdgcn_classf(d.x, kNormal) && __builtin_amdgcn_classf(d.y, kNormal) && __builtin_amdgcn_classf(d.z, kNormal) &&
+                      fabsf(d.x) < 0x1p+40f && fabsf(d.y) < 0x1p+40f && fabsf(d.z) < 0x1p+40f &&
+                      fabsf(d.x) > 0x1p-40f && fabsf(d.y) > 0x1p-40f && fabsf(d.z) > 0x1p-40f;
+    return o_ok && d_ok;
+}
+
+// A whole ray, for callers whose lanes all start together (the light-sample and shadow rays of the
+// shade kernel).  Returns false for a lane whose stack would have overflowed (its h is then unspecified).
+template <bool ANY, bool QUICK>
+__device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h) {
+    const uint32_t tid = threadIdx.x;
+    WideState w; w.cur = 0u; w.sp = 0u; w.best_slot = 0u;
+    bool ok = true;
+    while (w.cur != kWideEmpty) {
+        while (wide_at_node(w)) ok = wide_node_step(S, o, inv, h.t, w, tid) && ok;
+        if (wide_at_leaf(w)) wide_leaf_step<ANY, QUICK>(S, o, d, h, w, tid);
+    }
+    return ok;
+}
+
+template <bool ANY>
+__device__ __forceinline__ void traverse_wide(const SceneView& S, V3 o, V3 d, HitRec& h) {
+    bool d_small, d_normal;
+    dir_class(d, S.dir_bound, d_small, d_normal);
+    const bool tame = wide_tame(S, o, d);
+    bool redo = !tame;
+    if (tame) {
+        // wave-uniform choice of the arithmetic among the lanes that walk (tame directions are normal numbers)
+        const bool quick_det = __all(d_small), quick_inv = __all(d_normal);
+        const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
+        const bool ok = quick_det ? traverse_wide_walk<ANY, true>(S, o, d, inv, h) : traverse_wide_walk<ANY, false>(S, o, d, inv, h);
+        redo = !ok;
+    }
+    if (redo) {
+        h.t = __builtin_inff(); h.u = 0.0f; h.v = 0.0f; h.gtri = kInvalid;
+        traverse_lane<ANY>(S, o, d, h);
+    }
+}
+
+} // namespace orion_dev

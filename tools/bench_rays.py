@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Closest-hit throughput (Mrays/s) of the traversal kernels on device-resident ray batches,
 timed with the library's HIP events.  Usage: python tools/bench_rays.py [scene ...]
-Environment: RAYS_LOG2 (batch size, default 22), RAYS_ONLY (name of the one batch to run)."""
+Environment: RAYS_LOG2 (batch size, default 22), RAYS_ONLY (name of the one batch to run),
+RAYS_MODES (comma-separated traversal options to run, default "1,4,0,2")."""
 import os
 import sys
 import time
@@ -76,10 +77,18 @@ def main():
                 octant = (dd[:, 0] > 0).astype(np.int64) | ((dd[:, 1] > 0).astype(np.int64) << 1) | ((dd[:, 2] > 0).astype(np.int64) << 2)
                 order8 = np.argsort(key * 8 + octant, kind="stable")
                 batches["R2 bin+oct"] = (o2[perm][order8], d2[perm][order8])
-        for mode, tag in ((1, "lane"), (2, "wave")):
-            if tag == "wave" and model.n_triangles > 2000:
+        o5, d5 = raygen.box_rays(model, n, seed=6)
+        batches["R5 box"] = (o5, d5)
+        exact = {}                                            # results of the unculled per-lane walk, batch by batch
+        wanted = [int(x) for x in os.environ.get("RAYS_MODES", "1,4,0,2").split(",")]
+        for mode, tag in ((1, "lane"), (4, "wide"), (0, "auto"), (2, "wave")):
+            if mode not in wanted or (tag == "wave" and model.n_triangles > 2000):
                 continue
-            sc.set_option("traversal", mode)
+            try:
+                sc.set_option("traversal", mode)
+            except api.OrionError as e:
+                print(f"{name:9s} {tag:5s} not available: {e}", flush=True)
+                continue
             only = os.environ.get("RAYS_ONLY")                # run just this batch (counter passes)
             for bname, (o, d) in batches.items():
                 if only and bname != only:
@@ -92,7 +101,12 @@ def main():
                     sc.closest_hit(to, td, out)
                 st = sc.profile_read()["closest_hit"]
                 sc.profile(False)
-                print(f"{name:9s} {tag:5s} {bname:11s} rays {len(o):8d}  {st['items'] / st['ms'] / 1e3:9.1f} Mrays/s  ({st['ms'] / st['launches']:.3f} ms/launch)", flush=True)
+                same = ""
+                if tag == "lane":
+                    exact[bname] = out.clone()
+                elif bname in exact:
+                    same = "  same bits as lane: %s" % bool(torch.equal(out, exact[bname]))
+                print(f"{name:9s} {tag:5s} {bname:11s} rays {len(o):8d}  {st['items'] / st['ms'] / 1e3:9.1f} Mrays/s  ({st['ms'] / st['launches']:.3f} ms/launch){same}", flush=True)
         sc.close()
 
 
