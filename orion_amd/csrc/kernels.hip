@@ -85,6 +85,8 @@ struct OrionScene {
     uint32_t overlap_below = 4u << 20;    // start the next batch on the other lane once this few rays are left (0: never)
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
+    DevBuf s_work;                    // grab counter + chunk list of the large-scene ray queries
+    uint32_t resident_blocks = 1280;  // blocks of the wide-walk query kernel the device holds at once
     Lane lane[2];                     // lane[0].stream == stream
     hipEvent_t ev_upload = nullptr;   // after the upload of a host accumulator
     uint32_t tag = 0;                 // last tag handed out; a tag is used once per scene
@@ -265,16 +267,31 @@ void with_query_mode(int mode, F&& f) {
     else with_mode(mode, f);
 }
 
+// Ray queries on a large scene: the waves of a launch that just fills the chip draw rays from a global
+// counter (k_query_wide).  Left to choose, a first pass sends the 64-ray chunks that are coherent through the
+// wave-synchronous walk and lists the others.
+template <bool ANY>
+int launch_query_wide(OrionScene* s, bool adapt, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_hits, uint8_t* d_occ) {
+    const int kid = ANY ? ORION_KERNEL_ANY_HIT : ORION_KERNEL_CLOSEST_HIT;
+    const uint32_t n_chunks = (n + 63u) / 64u;
+    if (int rc = s->s_work.reserve(16 + (adapt ? (size_t)n_chunks * 4 : 0))) return rc;
+    uint32_t* work = static_cast<uint32_t*>(s->s_work.p);
+    uint32_t* chunks = work + 4;
+    HIP_TRY(hipMemsetAsync(work, 0, 16, s->stream));
+    // one block per kQueryGrab * 2 rays at most, and no more than the chip holds at once
+    const uint32_t want = (n + 2 * kQueryGrab - 1) / (2 * kQueryGrab);
+    const uint32_t grid = want < s->resident_blocks ? (want ? want : 1u) : s->resident_blocks;
+    if (adapt) launch(s, kid, 0, k_query_coherent<ANY>, dim3((n_chunks + kCoherentChunks - 1) / kCoherentChunks), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, chunks);
+    if (adapt) launch(s, kid, n, k_query_wide<ANY, true>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+    else launch(s, kid, n, k_query_wide<ANY, false>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_out) {
     const int qm = s->query_mode();
-    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) {
-        const dim3 grid((n + kQueryTile - 1) / kQueryTile);
-        if (qm == MODE_WIDE) launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_query_wide<false, false>, grid, dim3(kBlock), s->view, d_org, d_dir, n, d_out, (uint8_t*)nullptr);
-        else launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_query_wide<false, true>, grid, dim3(kBlock), s->view, d_org, d_dir, n, d_out, (uint8_t*)nullptr);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    with_query_mode(s->query_mode(), [&](auto M) {
+    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) return launch_query_wide<false>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, d_out, nullptr);
+    with_query_mode(qm, [&](auto M) {
         launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_closest_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     });
     HIP_TRY(hipGetLastError());
@@ -283,14 +300,8 @@ int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32
 
 int launch_anyhit(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, uint8_t* d_out) {
     const int qm = s->query_mode();
-    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) {
-        const dim3 grid((n + kQueryTile - 1) / kQueryTile);
-        if (qm == MODE_WIDE) launch(s, ORION_KERNEL_ANY_HIT, n, k_query_wide<true, false>, grid, dim3(kBlock), s->view, d_org, d_dir, n, (OrionHit*)nullptr, d_out);
-        else launch(s, ORION_KERNEL_ANY_HIT, n, k_query_wide<true, true>, grid, dim3(kBlock), s->view, d_org, d_dir, n, (OrionHit*)nullptr, d_out);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    with_query_mode(s->query_mode(), [&](auto M) {
+    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) return launch_query_wide<true>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, nullptr, d_out);
+    with_query_mode(qm, [&](auto M) {
         launch(s, ORION_KERNEL_ANY_HIT, n, k_anyhit_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     });
     HIP_TRY(hipGetLastError());
@@ -534,6 +545,12 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         v.dir_bound = (float)(bound * (1.0 - 1e-6));
     }
     s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
+    {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_query_wide<false, false>, kBlock, 0) == hipSuccess && per_cu > 0)
+            s->resident_blocks = (uint32_t)cus * (uint32_t)per_cu;
+    }
     for (const Mesh& dm : dmeshes) s->mesh_tri_base.push_back(dm.tri_base);
     *out = s;
     return 0;
@@ -546,7 +563,7 @@ int orion_hip_scene_destroy(OrionScene* s) {
     drain_profile(s);
     for (hipEvent_t e : s->pool) (void)hipEventDestroy(e);
     for (void* p : s->owned) (void)hipFree(p);
-    s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release();
+    s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release(); s->s_work.release();
     for (Lane& L : s->lane) {
         for (DevBuf& b : L.q) b.release();
         L.hits.release(); L.rad.release(); L.counter.release();

@@ -138,15 +138,27 @@ __global__ __launch_bounds__(kBlock) void k_anyhit_api(SceneView S, const float*
 
 // The ray queries of large scenes (MODE_WIDE, MODE_ADAPT_WIDE).  Incoherent rays take wildly different
 // numbers of steps through the tree (half of them a handful, one in a hundred over a hundred), and a wave
-// that holds 64 rays from start to end runs as long as its longest one with most lanes idle.  Here a block
-// owns a tile of kQueryTile rays and its lanes draw rays from it one at a time: whenever kRefillMin lanes
-// of a wave have finished theirs, they fetch new ones (one LDS atomic per wave and refill).
-// ADAPT: each wave first looks at the tile's 64-ray chunks in turn; a chunk whose rays leave one point in
-// nearly one direction (camera rays) goes through the wave-synchronous walk at once, the others join the
-// pool the lanes draw from.
-constexpr uint32_t kQueryRays = 8;                      // rays per thread of a tile
-constexpr uint32_t kQueryTile = kBlock * kQueryRays;
-constexpr uint32_t kRefillMin = 16;
+// that holds 64 rays from start to end runs as long as its longest one with most lanes idle.  Here the
+// waves of a launch that just fills the chip draw rays until none are left: a wave takes kQueryGrab
+// consecutive rays at a time from a global counter (one atomic per grab) and hands them to its lanes as
+// they finish, kRefillMin lanes at a time.
+//   work[0]: the grab counter (zero at launch), work[1]: number of listed chunks (LISTED only).
+// LISTED (MODE_ADAPT_WIDE): k_query_coherent has been over the batch first; 64-ray chunks whose rays leave
+// one point in nearly one direction (camera rays) went through the wave-synchronous walk there, and the
+// others are listed in `chunks` -- a grab is then one listed chunk.
+#ifndef ORION_REFILL_MIN
+#define ORION_REFILL_MIN 8
+#endif
+#ifndef ORION_LEAF_QUORUM
+#define ORION_LEAF_QUORUM 24
+#endif
+#ifndef ORION_QUERY_GRAB
+#define ORION_QUERY_GRAB 256
+#endif
+constexpr uint32_t kRefillMin = ORION_REFILL_MIN;       // lanes out of work before a wave fetches
+constexpr uint32_t kLeafQuorumWide = ORION_LEAF_QUORUM; // lanes waiting at a leaf before the wave turns to the triangles
+constexpr uint32_t kQueryGrab = ORION_QUERY_GRAB;       // rays a wave takes from the global counter at a time
+constexpr uint32_t kCoherentChunks = 16;                // 64-ray chunks per block of k_query_coherent
 
 template <bool ANY>
 __device__ __forceinline__ void query_store(const SceneView& S, uint32_t i, const HitRec& h, OrionHit* __restrict__ out, uint8_t* __restrict__ occ) {
@@ -160,79 +172,100 @@ __device__ __forceinline__ void query_store(const SceneView& S, uint32_t i, cons
     out[i] = r;
 }
 
-template <bool ANY, bool ADAPT>
-__global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float* __restrict__ org, const float* __restrict__ dir,
-                                                       uint32_t n, OrionHit* __restrict__ out, uint8_t* __restrict__ occ) {
-    __shared__ uint32_t s_next, s_nlist;
-    __shared__ uint8_t s_list[kQueryTile / 64];
-    const uint32_t tile0 = blockIdx.x * kQueryTile;
-    const uint32_t tile_n = min(kQueryTile, n - tile0);
-    const uint32_t lane = lane_id(), tid = threadIdx.x;
-    if (tid == 0) { s_next = 0u; s_nlist = 0u; }
+template <bool ANY>
+__global__ __launch_bounds__(kBlock) void k_query_coherent(SceneView S, const float* __restrict__ org, const float* __restrict__ dir, uint32_t n,
+                                                           OrionHit* __restrict__ out, uint8_t* __restrict__ occ,
+                                                           uint32_t* __restrict__ work, uint32_t* __restrict__ chunks) {
+    __shared__ uint32_t s_left[kCoherentChunks];
+    __shared__ uint32_t s_nleft, s_base;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_nleft = 0u;
     __syncthreads();
-    if (ADAPT) {
-        const uint32_t n_chunks = (tile_n + 63u) / 64u;
-        for (uint32_t chunk = tid >> 6; chunk < n_chunks; chunk += kBlock / 64) {
-            const uint32_t i = tile0 + chunk * 64u + lane;
-            const bool active = i < n;
-            V3 o = splat(0.0f), d = splat(1.0f);
-            if (active) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); }
-            if (wave_is_coherent(o, d, active)) {
-                HitRec h = miss_rec();
-                traverse_wave(S, o, d, h, active);
-                if (active) query_store<ANY>(S, i, h, out, occ);
-            } else if (lane == 0) {
-                s_list[atomicAdd(&s_nlist, 1u)] = (uint8_t)chunk;
-            }
+    const uint32_t n_chunks = (n + 63u) / 64u;
+    for (uint32_t k = wave; k < kCoherentChunks; k += kBlock / 64) {
+        const uint32_t chunk = blockIdx.x * kCoherentChunks + k;
+        if (chunk >= n_chunks) break;
+        const uint32_t i = chunk * 64u + lane;
+        const bool active = i < n;
+        V3 o = splat(0.0f), d = splat(1.0f);
+        if (active) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); }
+        if (wave_is_coherent(o, d, active)) {
+            HitRec h = miss_rec();
+            traverse_wave(S, o, d, h, active);
+            if (active) query_store<ANY>(S, i, h, out, occ);
+        } else if (lane == 0) {
+            s_left[atomicAdd(&s_nleft, 1u)] = chunk;
         }
-        __syncthreads();
     }
-    const uint32_t pool = ADAPT ? s_nlist * 64u : tile_n;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_nleft) s_base = atomicAdd(&work[1], s_nleft);
+    __syncthreads();
+    if (threadIdx.x < s_nleft) chunks[s_base + threadIdx.x] = s_left[threadIdx.x];
+}
+
+template <bool ANY, bool LISTED>
+__global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float* __restrict__ org, const float* __restrict__ dir, uint32_t n,
+                                                       OrionHit* __restrict__ out, uint8_t* __restrict__ occ,
+                                                       uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks) {
+    const uint32_t lane = lane_id(), tid = threadIdx.x;
+    const uint32_t n_listed = LISTED ? work[1] : 0u;
+    const uint32_t n_grabs = LISTED ? (n_listed + kQueryGrab / 64u - 1u) / (kQueryGrab / 64u) : (n + kQueryGrab - 1u) / kQueryGrab;
+    uint32_t g_next = 0u, g_end = 0u;    // the rays of the wave's current grab not handed out yet (wave-uniform)
+    uint32_t l_next = 0u, l_end = 0u;    // LISTED: the listed chunks of the grab not started yet
+    bool pool_empty = false;             // (wave-uniform)
 
     uint32_t ray = kInvalid;
     V3 o = splat(0.0f), d = splat(1.0f), inv = splat(1.0f);
     HitRec h = miss_rec();
     WideState w; w.cur = kWideEmpty; w.sp = 0u; w.best_slot = 0u;
-    bool quick_det = false, slow = false, exhausted = false;
+    bool quick_det = false, slow = false;
     for (;;) {
-        const bool idle = w.cur == kWideEmpty && !slow && !exhausted;
+        const bool idle = w.cur == kWideEmpty && !slow;
         const uint64_t mi = __ballot(idle);
-        const uint64_t busy = __ballot(w.cur != kWideEmpty || slow);
-        if (mi != 0ull && ((uint32_t)__popcll(mi) >= kRefillMin || busy == 0ull)) {
-            const int leader = __builtin_ctzll(mi);
-            uint32_t base = 0u;
-            if ((int)lane == leader) base = atomicAdd(&s_next, (uint32_t)__popcll(mi));
-            base = __shfl(base, leader);
-            if (idle) {
-                const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
-                if (idx < pool) {
-                    const uint32_t i = ADAPT ? tile0 + (uint32_t)s_list[idx >> 6] * 64u + (idx & 63u) : tile0 + idx;
-                    if (i < n) {
-                        o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i);
-                        bool d_small, d_normal;
-                        dir_class(d, S.dir_bound, d_small, d_normal);
-                        quick_det = d_small;
-                        inv = ray_inverse(d);
-                        h = miss_rec();
-                        ray = i;
-                        if (wide_tame(S, o, d)) { w.cur = 0u; w.sp = 0u; w.best_slot = 0u; }
-                        else slow = true;
-                    }
-                } else {
-                    exhausted = true;
+        const uint64_t busy = ~mi & __ballot(true);
+        if (!pool_empty && mi != 0ull && ((uint32_t)__popcll(mi) >= kRefillMin || busy == 0ull)) {
+            if (g_next == g_end && l_next == l_end) {   // a new grab
+                uint32_t g = 0u;
+                if (lane == 0u) g = atomicAdd(&work[0], 1u);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (g >= n_grabs) pool_empty = true;
+                else if (LISTED) { l_next = g * (kQueryGrab / 64u); l_end = min(n_listed, l_next + kQueryGrab / 64u); }
+                else { g_next = g * kQueryGrab; g_end = min(n, g_next + kQueryGrab); }
+            }
+            if (LISTED && g_next == g_end && l_next != l_end) { g_next = chunks[l_next] * 64u; g_end = min(n, g_next + 64u); l_next++; }
+            if (!pool_empty) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
+                const uint32_t i = g_next + rank;
+                if (idle && i < g_end) {
+                    o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i);
+                    bool d_small, d_normal;
+                    dir_class(d, S.dir_bound, d_small, d_normal);
+                    quick_det = d_small;
+                    inv = ray_inverse(d);
+                    h = miss_rec();
+                    ray = i;
+                    if (wide_tame(S, o, d)) { w.cur = 0u; w.sp = 0u; w.best_slot = 0u; }
+                    else slow = true;
                 }
+                g_next = min(g_end, g_next + (uint32_t)__popcll(mi));
             }
         }
         if (__ballot(w.cur != kWideEmpty || slow) == 0ull) {
-            if (__ballot(!exhausted) == 0ull) break;
+            if (pool_empty) break;
             continue;
         }
         // rays the wide walk does not take, and lanes whose stack overflowed: the unculled walk
         if (__any(slow)) {
             if (slow) { h = miss_rec(); traverse_lane<ANY>(S, o, d, h); slow = false; w.cur = kWideEmpty; }
         }
-        while (wide_at_node(w)) {
-            if (!wide_node_step(S, o, inv, h.t, w, tid)) slow = true;
+        // Node steps until nobody is at a node -- or until enough lanes wait at a leaf, or enough have run
+        // out of work to make fetching worthwhile: they would sit idle while the others walk on.
+        for (;;) {
+            const bool at_node = wide_at_node(w);
+            if (!__any(at_node)) break;
+            if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kLeafQuorumWide) break;
+            if (!pool_empty && (uint32_t)__popcll(__ballot(w.cur == kWideEmpty && !slow)) >= kRefillMin) break;
+            if (at_node && !wide_node_step(S, o, inv, h.t, w, tid)) slow = true;
         }
         const bool at_leaf = wide_at_leaf(w);
         const bool all_quick = __all(!at_leaf || quick_det);

@@ -33,11 +33,23 @@
 namespace orion_dev {
 
 constexpr int kWideBlock = 256;    // threads per block of every kernel that walks the wide tree
-constexpr int kWideStack = 16;     // stack entries per lane (LDS: 8 bytes each)
+#ifndef ORION_WIDE_STACK
+#define ORION_WIDE_STACK 16
+#endif
+constexpr int kWideStack = ORION_WIDE_STACK;     // stack entries per lane (LDS: 6 bytes each)
 
-// One lane's stack entry: what to visit and where its grown box begins along the ray.
+// One lane's stack entry: what to visit (4 bytes) and where its grown box begins along the ray, as the
+// upper half of the float rounded down (2 bytes: a bound from below is all the entry is used for).
 // [depth][thread]: a lane's entries sit in the same banks at every depth.
-__shared__ uint2 g_wide_stack[kWideStack][kWideBlock];
+__shared__ uint32_t g_wide_ref[kWideStack][kWideBlock];
+__shared__ uint16_t g_wide_t[kWideStack][kWideBlock];
+
+__device__ __forceinline__ void wide_push(uint32_t sp, uint32_t tid, uint32_t ref, float tmin) {
+    // Upper 16 bits: truncation rounds a positive float down; a negative entry distance (origin inside
+    // the box) becomes 0, which is below every best hit as well.
+    g_wide_ref[sp][tid] = ref;
+    g_wide_t[sp][tid] = (uint16_t)(__float_as_uint(fmaxf(tmin, 0.0f)) >> 16);
+}
 
 // (compiles to one v_cvt_f32_ubyteK)
 template <int K> __device__ __forceinline__ float byte_of(uint32_t w) { return (float)((w >> (8 * K)) & 0xFFu); }
@@ -53,8 +65,8 @@ __device__ __forceinline__ void wide_pop(WideState& w, float best, uint32_t tid)
     w.cur = kWideEmpty;
     while (w.sp) {
         w.sp--;
-        const uint2 e = g_wide_stack[w.sp][tid];
-        if (!(__uint_as_float(e.y) > best)) { w.cur = e.x; break; }
+        const float t = __uint_as_float((uint32_t)g_wide_t[w.sp][tid] << 16);
+        if (!(t > best)) { w.cur = g_wide_ref[w.sp][tid]; break; }
     }
 }
 
@@ -103,10 +115,10 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
     const uint32_t kn = t0 == tn ? 0u : (t1 == tn ? 1u : (t2 == tn ? 2u : 3u));
     const bool p0 = t0 < inf && kn != 0u, p1 = t1 < inf && kn != 1u, p2 = t2 < inf && kn != 2u, p3 = t3 < inf && kn != 3u;
     if (w.sp + (p0 ? 1u : 0u) + (p1 ? 1u : 0u) + (p2 ? 1u : 0u) + (p3 ? 1u : 0u) > (uint32_t)kWideStack) { w.cur = kWideEmpty; return false; }
-    if (p3) { g_wide_stack[w.sp][tid] = make_uint2(r3, __float_as_uint(t3)); w.sp++; }
-    if (p2) { g_wide_stack[w.sp][tid] = make_uint2(r2, __float_as_uint(t2)); w.sp++; }
-    if (p1) { g_wide_stack[w.sp][tid] = make_uint2(r1, __float_as_uint(t1)); w.sp++; }
-    if (p0) { g_wide_stack[w.sp][tid] = make_uint2(r0, __float_as_uint(t0)); w.sp++; }
+    if (p3) { wide_push(w.sp, tid, r3, t3); w.sp++; }
+    if (p2) { wide_push(w.sp, tid, r2, t2); w.sp++; }
+    if (p1) { wide_push(w.sp, tid, r1, t1); w.sp++; }
+    if (p0) { wide_push(w.sp, tid, r0, t0); w.sp++; }
     w.cur = kn == 0u ? r0 : (kn == 1u ? r1 : (kn == 2u ? r2 : r3));
     return true;
 }

@@ -79,6 +79,16 @@ def main():
                 batches["R2 bin+oct"] = (o2[perm][order8], d2[perm][order8])
         o5, d5 = raygen.box_rays(model, n, seed=6)
         batches["R5 box"] = (o5, d5)
+        if os.environ.get("RAYS_SORT"):                       # what ordering the rays by origin cell and direction octant is worth
+            lo, hi = raygen.scene_bounds(model)
+            bits = int(os.environ["RAYS_SORT"])
+            for bname in list(batches):
+                o, d = batches[bname]
+                cell = np.clip(((o - lo) / (hi - lo) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+                octant = (d[:, 0] > 0).astype(np.int64) | ((d[:, 1] > 0).astype(np.int64) << 1) | ((d[:, 2] > 0).astype(np.int64) << 2)
+                key = (((cell[:, 0] << bits | cell[:, 1]) << bits | cell[:, 2]) << 3) | octant
+                order = np.argsort(key, kind="stable")
+                batches[bname] = (o[order], d[order])
         exact = {}                                            # results of the unculled per-lane walk, batch by batch
         wanted = [int(x) for x in os.environ.get("RAYS_MODES", "1,4,0,2").split(",")]
         for mode, tag in ((1, "lane"), (4, "wide"), (0, "auto"), (2, "wave")):

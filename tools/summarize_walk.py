@@ -7,7 +7,7 @@ prefix, rays = sys.argv[1], float(sys.argv[2])
 agg = collections.defaultdict(float); n = collections.Counter()
 for f in glob.glob(prefix + "_pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_closest_api" in r["Kernel_Name"]:
+        if "k_closest_api" in r["Kernel_Name"] or "k_query_wide" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 L = max(n.values()) if n else 1
 print(f"launches counted: {L}")
@@ -23,5 +23,5 @@ if "TCP_TOTAL_CACHE_ACCESSES_sum" in agg:
     print(f"- L1 (TCP) accesses per ray: {g('TCP_TOTAL_CACHE_ACCESSES_sum') / rays:.1f}; L1->L2 read requests per ray: {g('TCP_TCC_READ_REQ_sum') / rays:.1f}; L2 hit rate {g('TCC_HIT_sum') / max(1, g('TCC_HIT_sum') + g('TCC_MISS_sum')):.3f}")
 for f in glob.glob(prefix + "_trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_closest_api" in r["Name"]:
+        if "k_closest_api" in r["Name"] or "k_query_wide" in r["Name"]:
             print(f"- kernel trace: {r['Name'][:60]} calls {r['Calls']} avg {float(r['AverageNs']) / 1e3:.1f} us")
