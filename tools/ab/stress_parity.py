@@ -24,7 +24,7 @@ def main():
         model = conftest.load_model(name)
         sc = api.Scene(model, device=0)
         orc = ob.OracleScene(model)
-        modes = (0, 1, 2, 3) if name == "cornell" else (0, 1, 2)
+        modes = (0, 1, 2, 3) if name == "cornell" else (0, 1, 2, 4)
         for seed in range(seeds):
             o, d = raygen.box_rays(model, n, seed=100 + seed)
             if seed % 2:   # coherent half: one origin, a narrow fan
