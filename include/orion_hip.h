@@ -150,6 +150,17 @@ int orion_hip_closest_hit(OrionScene* scene, const float* org_any, const float* 
 int orion_hip_any_hit(OrionScene* scene, const float* org_any, const float* dir_any,
                       uint32_t n, uint8_t* occluded_any);
 
+/* orion_hip_closest_hit for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same results as
+ * orion_hip_closest_hit.  org, dir and out must be DEVICE arrays; n is at most 16 777 216 (2^24) rays per
+ * call, larger batches are refused.  On large scenes the kernels' work words and chunk list (what the
+ * other entry point keeps in a buffer it allocates) live in a 1 MiB array inside the library's code
+ * object, one copy per GPU, held until the process ends.  The call makes no hipMalloc / hipFree and
+ * records no profiling events.  Every call on one GPU shares that GPU's array: calls that overlap on one
+ * GPU (two scenes, two threads) race -- serialise them. */
+int orion_hip_closest_hit_noalloc(OrionScene* scene, const float* org, const float* dir,
+                                  uint32_t n, OrionHit* out);
+
 /* Adds, for every pixel of the tile, the radiance of samples [spp_begin, spp_end)
  * to accum_rgba_any (width*height*4 floats: r, g, b sums and the sample count in
  * the fourth channel), in ascending sample order.  No 1/spp scaling: the caller

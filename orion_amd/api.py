@@ -90,6 +90,7 @@ def lib():
         L.orion_hip_scene_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.orion_hip_closest_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orion_hip_any_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orion_hip_closest_hit_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orion_hip_render.argtypes = [C.c_void_p, C.POINTER(_Camera), C.POINTER(_RenderParams), C.c_void_p]
         L.orion_hip_camera_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.POINTER(_Camera)]
         L.orion_hip_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -210,6 +211,16 @@ class Scene:
         if out is None:
             out = np.zeros(len(o), HIT_DTYPE)
         _check(lib().orion_hip_closest_hit(self.h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data))
+        return out
+
+    def closest_hit_noalloc(self, org, dir, out):
+        """orion_hip_closest_hit_noalloc: torch CUDA tensors only, the caller brings the output ([n, 5] int32)."""
+        import torch
+        n = org.shape[0]
+        assert org.dtype == torch.float32 and dir.dtype == torch.float32 and org.is_contiguous() and dir.is_contiguous()
+        assert out.dtype == torch.int32 and out.is_contiguous() and tuple(out.shape) == (n, 5)
+        _settle(org)
+        _check(lib().orion_hip_closest_hit_noalloc(self.h, org.data_ptr(), dir.data_ptr(), n, out.data_ptr()))
         return out
 
     def any_hit(self, org, dir, out=None):

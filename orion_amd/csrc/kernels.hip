@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -67,6 +68,33 @@ struct Lane {
 // so the stream always holds queued work and no launch waits on a host round trip.
 constexpr uint32_t kRing = 8, kLag = 2, kClearAhead = 3;
 static_assert(kLag + kClearAhead + 1 < kRing, "a slot must be read before it is cleared for reuse");
+
+// Scratch of orion_hip_closest_hit_noalloc: the ray-query kernels' work words (grab counter, number of
+// listed chunks) and the list of 64-ray chunks left to the wide walk -- what orion_hip_closest_hit keeps in
+// a buffer it allocates.  Every GPU the library runs on holds its own copy of this array until the process
+// ends; g_noalloc_scratch[device] is that copy's address, looked up once per device at scene creation.
+constexpr uint32_t kNoAllocMaxRays = 1u << 24;
+constexpr uint32_t kNoAllocWords = 64 + kNoAllocMaxRays / 64;     // 256 bytes of work words, then the chunk list (1 MiB)
+constexpr int kMaxDevices = 64;
+uint32_t* g_noalloc_scratch[kMaxDevices] = {};
+std::mutex g_noalloc_mutex;
+
+} // namespace
+
+static __device__ __align__(256) uint32_t scratch[kNoAllocWords];
+
+namespace {
+
+// With `device` current: the address of this device's copy of `scratch`.
+int resolve_noalloc_scratch(int device) {
+    if (device < 0 || device >= kMaxDevices) return 0;   // (such a device simply has no no-allocation entry point)
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (g_noalloc_scratch[device]) return 0;
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    g_noalloc_scratch[device] = static_cast<uint32_t*>(ptr);
+    return 0;
+}
 
 } // namespace
 
@@ -271,26 +299,46 @@ void with_query_mode(int mode, F&& f) {
 // counter (k_query_wide).  Left to choose, a first pass sends the 64-ray chunks that are coherent through the
 // wave-synchronous walk and lists the others.
 template <bool ANY>
-int launch_query_wide(OrionScene* s, bool adapt, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_hits, uint8_t* d_occ) {
+int launch_query_wide(OrionScene* s, bool adapt, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_hits, uint8_t* d_occ,
+                      uint32_t* work, bool plain) {
     const int kid = ANY ? ORION_KERNEL_ANY_HIT : ORION_KERNEL_CLOSEST_HIT;
     const uint32_t n_chunks = (n + 63u) / 64u;
-    if (int rc = s->s_work.reserve(16 + (adapt ? (size_t)n_chunks * 4 : 0))) return rc;
-    uint32_t* work = static_cast<uint32_t*>(s->s_work.p);
-    uint32_t* chunks = work + 4;
+    uint32_t* chunks = work + 64;   // 256 bytes of work words, then the list
     HIP_TRY(hipMemsetAsync(work, 0, 16, s->stream));
     // one block per kQueryGrab * 2 rays at most, and no more than the chip holds at once
     const uint32_t want = (n + 2 * kQueryGrab - 1) / (2 * kQueryGrab);
     const uint32_t grid = want < s->resident_blocks ? (want ? want : 1u) : s->resident_blocks;
-    if (adapt) launch(s, kid, 0, k_query_coherent<ANY>, dim3((n_chunks + kCoherentChunks - 1) / kCoherentChunks), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, chunks);
-    if (adapt) launch(s, kid, n, k_query_wide<ANY, true>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
-    else launch(s, kid, n, k_query_wide<ANY, false>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+    const dim3 cgrid((n_chunks + kCoherentChunks - 1) / kCoherentChunks);
+    if (plain) {   // no profiling events: nothing here may allocate
+        if (adapt) {
+            hipLaunchKernelGGL(k_query_coherent<ANY>, cgrid, dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_hits, d_occ, work, chunks);
+            hipLaunchKernelGGL((k_query_wide<ANY, true>), dim3(grid), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+        } else {
+            hipLaunchKernelGGL((k_query_wide<ANY, false>), dim3(grid), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+        }
+    } else {
+        if (adapt) launch(s, kid, 0, k_query_coherent<ANY>, cgrid, dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, chunks);
+        if (adapt) launch(s, kid, n, k_query_wide<ANY, true>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+        else launch(s, kid, n, k_query_wide<ANY, false>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+    }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The scene's own work buffer for the wide ray queries (allocated on first use, grown as needed).
+int query_work(OrionScene* s, bool adapt, uint32_t n, uint32_t** work) {
+    if (int rc = s->s_work.reserve(256 + (adapt ? (size_t)((n + 63u) / 64u) * 4 : 0))) return rc;
+    *work = static_cast<uint32_t*>(s->s_work.p);
     return 0;
 }
 
 int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_out) {
     const int qm = s->query_mode();
-    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) return launch_query_wide<false>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, d_out, nullptr);
+    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) {
+        uint32_t* work = nullptr;
+        if (int rc = query_work(s, qm == MODE_ADAPT_WIDE, n, &work)) return rc;
+        return launch_query_wide<false>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, d_out, nullptr, work, false);
+    }
     with_query_mode(qm, [&](auto M) {
         launch(s, ORION_KERNEL_CLOSEST_HIT, n, k_closest_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     });
@@ -300,7 +348,11 @@ int launch_closest(OrionScene* s, const float* d_org, const float* d_dir, uint32
 
 int launch_anyhit(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, uint8_t* d_out) {
     const int qm = s->query_mode();
-    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) return launch_query_wide<true>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, nullptr, d_out);
+    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) {
+        uint32_t* work = nullptr;
+        if (int rc = query_work(s, qm == MODE_ADAPT_WIDE, n, &work)) return rc;
+        return launch_query_wide<true>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, nullptr, d_out, work, false);
+    }
     with_query_mode(qm, [&](auto M) {
         launch(s, ORION_KERNEL_ANY_HIT, n, k_anyhit_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), s->view, d_org, d_dir, n, d_out);
     });
@@ -500,6 +552,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return fail(2, "no HIP device"); }
     DeviceGuard guard(device);
     if (!guard.ok) return fail(2, "cannot select HIP device " + std::to_string(device));
+    if (int rc = resolve_noalloc_scratch(device)) return rc;
     OrionScene* s = new OrionScene;
     s->device = device;
     auto bail = [&](int rc) { orion_hip_scene_destroy(s); return rc; };
@@ -639,6 +692,29 @@ int orion_hip_any_hit(OrionScene* s, const float* org_any, const float* dir_any,
     }
     if (int rc = launch_anyhit(s, d_org, d_dir, n, d_out)) return rc;
     if (!out_dev) HIP_TRY(hipMemcpyAsync(occluded_any, d_out, n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int orion_hip_closest_hit_noalloc(OrionScene* s, const float* d_org, const float* d_dir, uint32_t n, OrionHit* d_out) {
+    if (!s) return fail(1, "closest_hit_noalloc: scene is null");
+    if (n == 0) return 0;
+    if (!d_org || !d_dir || !d_out) return fail(1, "closest_hit_noalloc: null array");
+    if (n > kNoAllocMaxRays) return fail(1, "closest_hit_noalloc: at most 16777216 rays per call");
+    DeviceGuard guard(s->device);
+    if (!is_device_ptr(d_org) || !is_device_ptr(d_dir) || !is_device_ptr(d_out))
+        return fail(1, "closest_hit_noalloc: the arrays must be device memory (staging host arrays would need an allocation)");
+    const int qm = s->query_mode();
+    if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) {
+        uint32_t* work = (s->device >= 0 && s->device < kMaxDevices) ? g_noalloc_scratch[s->device] : nullptr;
+        if (!work) return fail(2, "closest_hit_noalloc: no scratch on this device");
+        if (int rc = launch_query_wide<false>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, d_out, nullptr, work, true)) return rc;
+    } else {   // the other walks keep nothing beyond their inputs and outputs
+        with_query_mode(qm, [&](auto M) {
+            hipLaunchKernelGGL(k_closest_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
+        });
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
