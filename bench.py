@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""Headline benchmark: the Cornell-box BRDF path tracer at 1920x1080, depth 100, 2 light samples
+"""Headline benchmark: the Cornell-box BRDF path tracer at 1920x1080, 2048 spp, depth 100, 2 light samples
 (the README render of the reference, BASELINE.json configs[1]) on N MI355X GPUs of one node.
 
-A step renders `--spp-per-step` samples of every pixel on each rank (ranks own disjoint sample
-ranges; weak scaling) into a device-resident accumulator, followed for N > 1 by one RCCL sum of
-the accumulators -- the only exchange the workload has.  The sum runs asynchronously while the next
-step renders into a second accumulator; the timed region ends when every sum has finished.
-value = pixel-samples/s over all ranks.
+A step is ONE FULL FRAME: 2048 samples of every pixel, split over the ranks by sample index (rank r renders
+samples [2048 r / N, 2048 (r + 1) / N) of the whole image: strong scaling), each rank into a device-resident
+accumulator, followed for N > 1 by one RCCL sum of the accumulators -- the only exchange the workload has.
+The sum runs asynchronously while the next frame renders into a second accumulator; the timed region ends
+when every sum has finished.  ms_per_step is therefore the frame's wall time, value = pixel-samples/s over
+all ranks.
 
     python bench.py --gpus 1 --steps 4 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
-  roofline      HBM roofline of the dominant kernel from live HIP-event timings
+  roofline      HBM roofline of the dominant kernel, from HIP-event timings of a separate profiled pass
+                (one batch at a time, so that no launch shares the chip with another batch's)
+  issue         the bound that actually holds: vector-instruction issue, against the guide's and the measured rate
+  ray_batches   closest-hit Mrays/s of the ray-query entry point on R1/R2/R3 batches of five scenes
   cpu_baseline  the oracle's render of a bounded sample of the same frame on the host cores
-  rays          traversal throughput (closest-hit queries/s) over the timed region
 """
 import argparse
 import json
@@ -32,7 +35,12 @@ MAX_DEPTH, LIGHT_SAMPLES, FULL_SPP = 100, 2, 2048
 CAMERA = ([-0.10141, 1, 3.00498], [-0.10141, 1, 2.00498], [0, 1, 0], 1.0)   # assets/cornell-box.rtc
 PUBLISHED_SAMPLES_PER_S = 1920 * 1080 * 2048 / 5126.4                        # reference README.md:38-46
 HBM_PEAK_GBS = 8000.0                                                        # MI355X HBM3E peak
-VALU_PEAK_GINSTR_S = 1024 * 2.4 / 2.84                                       # measured sustained wave64 VALU issue rate, G/s
+# Vector-instruction issue, wave64 instructions per second over 1024 SIMDs: the guide's figure (one per 2 cycles per
+# SIMD at the nominal 2.4 GHz) and what tools/micro/valu_rate.hip sustains on the box with independent FMA chains,
+# 8 waves per SIMD (one per 2.975 nominal cycles; in-kernel counters show why: under that load the shader clock
+# drops to 1.86 GHz, which makes it one per 2.3 real cycles).
+VALU_GUIDE_GINSTR_S = 1024 * 2.4 / 2.0
+VALU_MEASURED_GINSTR_S = 1024 * 2.4 / 2.975
 # Algorithmic queue bytes: 32 B ray record read + 32 B hit record written per closest-hit query;
 # a shaded path vertex adds L*E such queries for its light samples and 48 B + 48 B of path state.
 BYTES_PER_RAY = 64
@@ -66,17 +74,85 @@ def cpu_baseline(model, cam, target_s=12.0):
             "box_tests_per_sample": float(counters[0]) / (w * h * 4), "triangle_tests_per_sample": float(counters[1]) / (w * h * 4)}
 
 
+def ray_batches(api, log2_rays=20, log2_large=22):
+    """Closest-hit throughput of the ray-query entry point (device-resident rays, the library's HIP events) on the
+    R1 / R2 / R3 batches of five scenes, with the HBM fraction of the 64 algorithmic bytes per ray."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    import raygen
+    n = 1 << log2_rays
+    out = {"rays_per_batch": n, "bytes_per_ray": BYTES_PER_RAY,
+           "note": "R1 jittered primary rays of random pixels (1920x1080 camera framing the scene), R2 cosine-weighted bounce rays "
+                   "from their hit points in random order, R3 rays from those points towards uniform surface points; "
+                   "Mrays/s = rays / average launch time over 5 launches (HIP events); hbm_frac = Mrays/s x 64 B / 8 TB/s"}
+    for name in ("cornell", "view_test", "hindu", "nanosuit", "soup"):
+        model = conftest.load_model(name)
+        sc = api.Scene(model, device=torch.cuda.current_device())
+        eye, look, up, yv = CAMERA if name == "cornell" else raygen.default_camera(model)
+        cam = api.camera_vectors(eye, look, up, yv, W / H)
+        o1, d1 = raygen.primary_rays(cam, W, H, n, seed=1)
+        h = sc.closest_hit(o1, d1)
+        nrm = np.zeros((n, 3), np.float32)
+        for mi, m in enumerate(model.meshes):
+            sel = np.where(h["mesh"] == mi)[0]
+            if len(sel):
+                nrm[sel] = m.vertices[m.indices[3 * h["tri"][sel]], 3:6]
+        batches = {"R1": (o1, d1)}
+        o2, d2 = raygen.bounce_rays(o1, d1, np.stack([h["mesh"], h["tri"]], 1), np.stack([h["t"], h["u"], h["v"]], 1), nrm, seed=2)
+        if len(o2) > 1000:
+            rep = int(np.ceil(n / len(o2)))
+            perm = np.random.default_rng(5).permutation(n)
+            o2 = np.tile(o2, (rep, 1))[:n][perm]; d2 = np.tile(d2, (rep, 1))[:n][perm]
+            batches["R2"] = (o2, d2)
+            batches["R3"] = raygen.rays_to_surface(o2, model, seed=3)
+        res = {"triangles": int(model.n_triangles)}
+        for bname, (o, d) in batches.items():
+            to, td = torch.from_numpy(np.ascontiguousarray(o)).cuda(), torch.from_numpy(np.ascontiguousarray(d)).cuda()
+            hits = torch.empty((n, 5), dtype=torch.int32, device="cuda")
+            sc.closest_hit(to, td, hits)
+            sc.profile(True)
+            for _ in range(5):
+                sc.closest_hit(to, td, hits)
+            st = sc.profile_read()["closest_hit"]
+            sc.profile(False)
+            mrays = 5 * n / st["ms"] / 1e3
+            res[bname] = {"Mrays_per_s": mrays, "hbm_frac": mrays * 1e6 * BYTES_PER_RAY / (HBM_PEAK_GBS * 1e9),
+                          "hit_rate": float((hits[:, 0] != -1).float().mean())}
+            if model.n_triangles > 2000:
+                # Large scenes: also 2^22 rays (the batch tiled four times in a fresh random order).  Their walk hands rays to
+                # lanes as they finish, and a batch has to be several times the 0.4 M lanes of the chip before the longest
+                # rays (ten times the median number of steps) stop deciding when the launch ends.
+                big = 1 << log2_large
+                perm = torch.randperm(big, device="cuda") % n
+                bo, bd = to[perm].contiguous(), td[perm].contiguous()
+                bh = torch.empty((big, 5), dtype=torch.int32, device="cuda")
+                sc.closest_hit(bo, bd, bh)
+                sc.profile(True)
+                for _ in range(5):
+                    sc.closest_hit(bo, bd, bh)
+                st = sc.profile_read()["closest_hit"]
+                sc.profile(False)
+                mr = 5 * big / st["ms"] / 1e3
+                res[bname]["Mrays_per_s_4Mi"] = mr
+                res[bname]["hbm_frac_4Mi"] = mr * 1e6 * BYTES_PER_RAY / (HBM_PEAK_GBS * 1e9)
+        out[name] = res
+        sc.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=128, help="samples per pixel per rank per step (32 = one 64 Mi-path batch at FHD)")
+    ap.add_argument("--spp", type=int, default=FULL_SPP, help="samples per pixel of a frame (one step); the headline is 2048")
     ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
     ap.add_argument("--tail-paths", type=int, default=-1, help="override the library's tail hand-over threshold (A/B runs)")
     ap.add_argument("--overlap-below", type=int, default=-1, help="override the library's two-lane overlap threshold (A/B runs; 0 = one lane)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not collect per-kernel HIP-event timings")
+    ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (per-kernel HIP-event timings, roofline)")
+    ap.add_argument("--no-ray-batches", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
@@ -112,15 +188,16 @@ def main():
         scene.set_option("overlap_below", args.overlap_below)
     accums = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
     pending = [None] * len(accums)
-    spp = args.spp_per_step
+    spp = args.spp
+    s_begin, s_end = spp * rank // world, spp * (rank + 1) // world     # this rank's share of every frame
 
     def step(index):
         k = index % len(accums)
         if pending[k] is not None:       # the sum that last used this accumulator
             pending[k].wait(); pending[k] = None
         accums[k].zero_()
-        base = (index * world + rank) * spp
-        scene.render(cam, W, H, base, base + spp, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accums[k])
+        # (every frame is rendered with the same sample indices: the frames of the timed region are repetitions)
+        scene.render(cam, W, H, s_begin, s_end, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accums[k])
         if world > 1:                    # the frame's one exchange: sum of the radiance accumulators
             pending[k] = dist.all_reduce(accums[k], async_op=True)
 
@@ -135,7 +212,6 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    scene.profile(not args.no_profile)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -146,80 +222,99 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    stats = scene.profile_read()
-    scene.profile(False)
 
-    samples = W * H * spp * args.steps * world
+    samples = W * H * spp * args.steps
     value = samples / dt
     out = {
-        "metric": "samples/s (pixel-samples per second, Cornell box 1920x1080 BRDF path tracer)",
+        "metric": "samples/s (pixel-samples per second, Cornell box 1920x1080 BRDF path tracer, %d-spp frames)" % spp,
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": value / PUBLISHED_SAMPLES_PER_S, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cornell-box BRDF path tracer 1920x1080, max depth 100, 2 light samples "
-                               "(BASELINE.json configs[1]); one step = %d spp of the full frame per GPU" % spp,
-                   "spp_per_step_per_gpu": spp, "seed": 1, "rng": "philox4x32-10 counter",
-                   "sharding": "sample-index ranges per rank + one RCCL all-reduce of the accumulator per step"},
-        "projected_wall_s_2048spp": W * H * FULL_SPP / value,
+        "config": {"workload": "cornell-box BRDF path tracer 1920x1080, %d spp, max depth 100, 2 light samples "
+                               "(BASELINE.json configs[1], the reference's README render); one step = one full frame" % spp,
+                   "spp": spp, "spp_per_gpu": s_end - s_begin, "seed": 1, "rng": "philox4x32-10 counter",
+                   "sharding": "sample-index ranges per rank + one RCCL all-reduce of the accumulator per frame"},
+        "frame_wall_s": dt / max(1, args.steps),
+        "per_gpu_samples_per_s": value / world,
     }
     if rank == 0:
         E = sum(1 for m in model.meshes if np.any(model.materials[m.material].emissive != 0))
-        # units per kernel: k_extend processes rays; k_shade processes the vertices that hit
-        vertices = stats["shadow"]["items"] // max(1, LIGHT_SAMPLES * E)
-        units = {"closest_hit": ("k_extend", stats["closest_hit"]["items"], BYTES_PER_RAY),
-                 "shade": ("k_shade", vertices, BYTES_PER_RAY * LIGHT_SAMPLES * E + BYTES_PER_VERTEX_STATE)}
-        pmc = {}
-        try:   # HBM bytes per unit measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (see profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-        except OSError:
-            pass
-        kern = {}
-        for name, (kname, items, per_item) in units.items():
-            st = stats[name]
-            if st["launches"] and st["ms"] > 0:
-                launches = st["launches"]
-                alg_per_launch = items * per_item / launches
-                avg_ms = st["ms"] / launches
-                kern[kname] = {"launches": launches, "units": items, "ms": st["ms"], "avg_launch_ms": avg_ms,
-                               "algorithmic_bytes_per_unit": per_item, "algorithmic_bytes_per_launch": alg_per_launch,
-                               "algorithmic_GBs": alg_per_launch / (avg_ms * 1e-3) / 1e9}
-                if kname in pmc:
-                    per = pmc[kname]["hbm_read_bytes_per_item"] + pmc[kname]["hbm_write_bytes_per_item"]
-                    kern[kname]["pmc_hbm_bytes_per_launch"] = per * items / launches
-        if kern:
-            dom = max(kern, key=lambda k: kern[k]["ms"])
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["algorithmic_GBs"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": kern[dom]["algorithmic_GBs"] / HBM_PEAK_GBS,
-                               "traffic": kern[dom].get("pmc_hbm_bytes_per_launch"),
-                               "note": "achieved = algorithmic bytes per launch / average launch duration (HIP events on the "
-                                       "library's stream over the timed region); traffic = HBM bytes per launch from the PMC passes "
-                                       "in profiles/ (FETCH_SIZE doubled per the gfx950 correction). The kernel is bound by "
-                                       "instruction issue (one VALU instruction per 3.2 cycles per SIMD against a measured "
-                                       "sustained 2.84), not by HBM.  Two batches are in flight at batch boundaries, so a launch's "
-                                       "duration includes the time it shares the chip with the other batch's launches."}
-            out["kernels"] = kern
-            if all("valu_wave_instructions_per_item" in pmc.get(k, {}) for k in kern):
-                # what actually bounds the step: vector-instruction issue.  Instructions per ray / vertex from the
-                # counter passes in profiles/, the chip's sustained rate from tools/micro/valu_rate.hip
-                # (one wave64 instruction per 2.84 cycles per SIMD, 1024 SIMDs at 2.4 GHz).
-                instr = sum(pmc[k]["valu_wave_instructions_per_item"] * kern[k]["units"] for k in kern)
-                out["issue"] = {"bound": "valu issue", "achieved": instr / dt / 1e9, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave64 instructions/s",
-                                "frac": instr / dt / 1e9 / VALU_PEAK_GINSTR_S,
-                                "note": "k_extend + k_shade vector instructions of rank 0 over the timed region / wall time"}
-            rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
-            out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
-                           "Mrays_per_s_per_gpu": rays / dt / 1e6,
-                           "note": "closest-hit queries traced by rank 0 over the timed region / wall time"}
+        if not args.no_profile:
+            # The profiled pass: 128 spp of the same frame, batches one at a time (under the two-lane overlap of the timed
+            # region a launch's duration includes the time it shares the chip with the other batch's launches).
+            scene.set_option("overlap_below", 0)
+            scene.profile(True)
+            accums[0].zero_()
+            t1 = time.perf_counter()
+            scene.render(cam, W, H, 0, 128, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accums[0])
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t1
+            stats = scene.profile_read()
+            scene.profile(False)
+            # units per kernel: k_extend processes rays; k_shade processes the vertices that hit
+            vertices = stats["shadow"]["items"] // max(1, LIGHT_SAMPLES * E)
+            units = {"closest_hit": ("k_extend", stats["closest_hit"]["items"], BYTES_PER_RAY),
+                     "shade": ("k_shade", vertices, BYTES_PER_RAY * LIGHT_SAMPLES * E + BYTES_PER_VERTEX_STATE)}
+            pmc = {}
+            for f in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+                try:   # HBM bytes per unit measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (see profiles/)
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", f)))
+                    break
+                except OSError:
+                    pass
+            kern = {}
+            for name, (kname, items, per_item) in units.items():
+                st = stats[name]
+                if st["launches"] and st["ms"] > 0:
+                    launches = st["launches"]
+                    alg_per_launch = items * per_item / launches
+                    avg_ms = st["ms"] / launches
+                    kern[kname] = {"launches": launches, "units": items, "ms": st["ms"], "avg_launch_ms": avg_ms,
+                                   "algorithmic_bytes_per_unit": per_item, "algorithmic_bytes_per_launch": alg_per_launch,
+                                   "algorithmic_GBs": alg_per_launch / (avg_ms * 1e-3) / 1e9}
+                    if kname in pmc:
+                        per = pmc[kname]["hbm_read_bytes_per_item"] + pmc[kname]["hbm_write_bytes_per_item"]
+                        kern[kname]["pmc_hbm_bytes_per_launch"] = per * items / launches
+            if kern:
+                dom = max(kern, key=lambda k: kern[k]["ms"])
+                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["algorithmic_GBs"], "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": kern[dom]["algorithmic_GBs"] / HBM_PEAK_GBS,
+                                   "traffic": kern[dom].get("pmc_hbm_bytes_per_launch"),
+                                   "note": "achieved = algorithmic bytes per launch / average launch duration (HIP events on the library's "
+                                           "stream) in a separate profiled pass of 128 spp of the same frame, one batch at a time; traffic = "
+                                           "HBM bytes per launch from the PMC passes in profiles/ (FETCH_SIZE doubled per the gfx950 "
+                                           "correction).  The kernel is bound by instruction issue, not by HBM: see `issue`."}
+                out["kernels"] = kern
+                out["profiled_pass"] = {"spp": 128, "wall_s": dtp, "samples_per_s": W * H * 128 / dtp}
+                if all("valu_wave_instructions_per_item" in pmc.get(k, {}) for k in kern):
+                    # what actually bounds the step: vector-instruction issue.  Instructions per ray / vertex from the counter
+                    # passes in profiles/, over the kernels' own time in the profiled pass.
+                    instr = sum(pmc[k]["valu_wave_instructions_per_item"] * kern[k]["units"] for k in kern)
+                    busy_s = sum(kern[k]["ms"] for k in kern) * 1e-3
+                    ach = instr / busy_s / 1e9
+                    out["issue"] = {"bound": "valu issue", "achieved": ach, "unit": "G wave64 instructions/s",
+                                    "peak_guide": VALU_GUIDE_GINSTR_S, "frac_guide": ach / VALU_GUIDE_GINSTR_S,
+                                    "peak_measured": VALU_MEASURED_GINSTR_S, "frac_measured": ach / VALU_MEASURED_GINSTR_S,
+                                    "note": "k_extend + k_shade vector instructions (counter passes in profiles/) over their summed launch time in the "
+                                            "profiled pass; peak_guide = one wave64 instruction per 2 cycles per SIMD at 2.4 GHz, peak_measured = "
+                                            "what independent FMA chains sustain on the box (tools/micro/valu_rate.hip: one per 2.975 nominal cycles, "
+                                            "the shader clock dropping to 1.86 GHz under that load)"}
+                rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
+                out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
+                               "per_sample": rays / (W * H * 128),
+                               "Mrays_per_s_per_gpu": rays / (W * H * 128) * value / world / 1e6,
+                               "note": "closest-hit queries per pixel-sample (profiled pass) x the timed region's samples/s per GPU"}
+        if not args.no_ray_batches:
+            out["ray_batches"] = ray_batches(api)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cb = cpu_baseline(model, cam)
             if "rays" in out:   # the algorithm's work per closest-hit query (reference counters: orion/avx/sbvh.cpp:8-12)
-                rays_per_sample = (out["rays"]["extend_rays"] + out["rays"]["light_sample_rays"]) / (W * H * spp * args.steps)
-                out["rays"]["per_sample"] = rays_per_sample
-                out["rays"]["box_tests_per_ray"] = cb["box_tests_per_sample"] / rays_per_sample
-                out["rays"]["triangle_tests_per_ray"] = cb["triangle_tests_per_sample"] / rays_per_sample
+                out["rays"]["box_tests_per_ray"] = cb["box_tests_per_sample"] / out["rays"]["per_sample"]
+                out["rays"]["triangle_tests_per_ray"] = cb["triangle_tests_per_sample"] / out["rays"]["per_sample"]
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

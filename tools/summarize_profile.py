@@ -65,9 +65,11 @@ def main():
         d = json.load(open(prefix + "trace/bench.json"))
         # The counter passes run the same command as the traced one, and the counters also see the
         # warm-up steps, which bench.py's unit counts leave out.
-        scale = (d["steps"] + d["warmup"]) / d["steps"]
+        # bench.py's unit counts are those of its profiled pass (128 spp of the frame); the counter passes run
+        # steps + warmup frames of config.spp samples and no profiled pass.
+        scale = (d["steps"] + d["warmup"]) * d["config"]["spp"] / 128.0
         units = {"k_extend": d["kernels"]["k_extend"]["units"] * scale, "k_shade": d["kernels"]["k_shade"]["units"] * scale}
-        note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 2 --warmup 1; FETCH_SIZE doubled "
+        note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --spp 128 --steps 2 --warmup 1; FETCH_SIZE doubled "
                 "(gfx950 counts half the bytes of wide coalesced reads); item = ray for k_extend, shaded vertex for k_shade")
         traffic = {}
         for k, n in units.items():
