@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -232,7 +233,15 @@ def load_model(obj_path: str, strategy: int = MEDIAN, load_textures: bool = Fals
             if m.map_diffuse:
                 p = os.path.join(model.directory, m.map_diffuse)
                 if p not in cache:
-                    cache[p] = load_image(p)
+                    try:
+                        cache[p] = load_image(p)
+                    except OSError as e:
+                        # The reference prints and goes on with a texture that has no texels (orion/texture.hpp:35-38);
+                        # fetching from it is undefined there.  Here the material keeps its solid colour.
+                        print(f"orion_amd: cannot load texture {p}: {e}", file=sys.stderr)
+                        cache[p] = None
+                if cache[p] is None:
+                    continue
                 m.tex_diffuse = cache[p]
                 if m.map_specular:
                     m.tex_specular = cache[p]

@@ -173,6 +173,20 @@ def test_image_readers_match_the_references_decoder(tmp_path):
         assert np.array_equal(got, want), n
 
 
+def test_nanosuit_colour_maps_decode_to_the_references_texels():
+    """The five 1024x1024 RGBA maps and the 128x128 glass map of the nanosuit (the reference's own data
+    files) through the host layer's PNG reader: the texels the reference's decoder returned for them
+    (fingerprints made by tests/golden/make_nanosuit_map_golden.py through oracle/_ref)."""
+    import hashlib
+    import json
+    want = json.load(open(os.path.join(conftest.GOLDEN, "nanosuit_maps_stb.json")))
+    assert len(want) == 6
+    for name, w in want.items():
+        t = host.load_png(os.path.join(conftest.ASSETS, "nanosuit2", name)).data
+        assert t.shape == (w["height"], w["width"], w["channels"]), name
+        assert hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest() == w["sha256"], name
+
+
 def test_jpeg_reader_refuses_what_it_cannot_decode(tmp_path):
     from PIL import Image
     im = Image.fromarray(np.random.default_rng(1).integers(0, 256, (16, 16, 3), dtype=np.uint8), "RGB")

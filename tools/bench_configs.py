@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CONFIGS = [("c0_cornell_point_256", 16, 1, 16), ("c1_cornell_brdf_fhd", 2048, 2, 64), ("c2_view_test_fhd", 256, 1, 64),
-           ("c3_nanosuit_fhd", 512, 1, 32), ("c4_hindu_4k", 1024, 1, 16)]
+           ("c3_nanosuit_fhd", 512, 1, 32), ("c3b_nanosuit_bounce_fhd", 512, 1, 32), ("c4_hindu_4k", 1024, 1, 16)]
 
 
 def main():
@@ -23,7 +23,7 @@ def main():
     for name, spp_full, ls, spp in CONFIGS:
         if only and name not in only:
             continue
-        fr = api.load_frame(os.path.join(ROOT, "configs", name + ".rtc"), load_textures=False)
+        fr = api.load_frame(os.path.join(ROOT, "configs", name + ".rtc"), load_textures=True)   # (hindu's JPEG is not in the tree: solid colour)
         W, H = fr.rtc.xres, fr.rtc.yres
         sc = api.Scene(fr.model, device=0)
         forced = int(os.environ.get("TRAVERSAL", "0"))     # A/B runs: 1 per-lane, 2 wave-synchronous
@@ -40,7 +40,7 @@ def main():
         st = sc.profile_read()
         rays = st["closest_hit"]["items"] + st["shadow"]["items"]
         n_ops = sum(len(m.nodes) for m in fr.model.meshes)
-        mode = {1: "per-lane", 2: "wave-synchronous"}.get(forced) or ("wave-synchronous" if n_ops <= 384 else "per-lane, primary rays wave-synchronous")
+        mode = {1: "per-lane", 2: "wave-synchronous", 4: "wide tree"}.get(forced) or ("wave-synchronous" if n_ops <= 384 else "wide tree, primary rays wave-synchronous")
         print(f"| {name} | {W}x{H} | {fr.rtc.recursion_level} | {mode} | {spp} | {W * H * spp / dt / 1e6:.1f} | {rays / dt / 1e6:.1f} | "
               f"{W * H * spp_full / (W * H * spp / dt):.2f} s |", flush=True)
         sc.close()

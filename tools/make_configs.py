@@ -21,7 +21,10 @@ CONFIGS = [
      "point-light ray tracer (the commented-out light of the asset moved inside the box)"),
     ("c1_cornell_brdf_fhd", "cornell-box.rtc", 1920, 1080, 100, [], 2048, 2, "README render: BRDF path tracer"),
     ("c2_view_test_fhd", "view_test.rtc", 1920, 1080, 1, None, 256, 1, "two-material quad scene, Phong + one mirror bounce"),
-    ("c3_nanosuit_fhd", "nanosuit.rtc", 1920, 1080, 0, None, 512, 1, "19 058 triangles, six meshes"),
+    ("c3_nanosuit_fhd", "nanosuit.rtc", 1920, 1080, 0, None, 512, 1, "19 058 triangles, six meshes, five PNG colour maps; depth 0 as the asset has it: primary and shadow rays"),
+    ("c3b_nanosuit_bounce_fhd", "nanosuit.rtc", 1920, 1080, 4, None, 512, 1,
+     "the same frame with four mirror bounces weighted by the specular texel (the map the reference installs there is the DIFFUSE "
+     "image, orion/model.cpp:186-187): incoherent secondary rays through the deep trees"),
     ("c4_hindu_4k", "hindu.rtc", 3840, 2160, 0, None, 1024, 1, "tile + sample sharded over 8 GPUs"),
 ]
 
