@@ -120,6 +120,29 @@ def camera_vectors(eye, look_at, up, y_view: float, aspect: float) -> np.ndarray
     return np.array(list(cam.eye) + list(cam.front) + list(cam.right) + list(cam.up), np.float32)
 
 
+def _array_ptr(x, what: str, shape, torch_dtype: str, np_dtype, device: Optional[int] = None) -> int:
+    """Address of a caller's array after checking what the library takes on trust: element type, C-contiguity,
+    shape (None = any extent) and, for torch tensors, the device.  Raises OrionError on a mismatch -- the
+    kernels would otherwise read or write out of bounds."""
+    if _is_torch(x):
+        import torch
+        ok = x.dtype == getattr(torch, torch_dtype) and x.is_contiguous() and x.is_cuda
+        if ok and device is not None and device >= 0:
+            ok = x.device.index == device
+        nbytes_shape = tuple(x.shape)
+    else:
+        ok = isinstance(x, np.ndarray) and x.dtype == np_dtype and x.flags["C_CONTIGUOUS"]
+        nbytes_shape = tuple(x.shape) if isinstance(x, np.ndarray) else ()
+    if ok and shape is not None:
+        ok = len(nbytes_shape) == len(shape) and all(s is None or s == t for s, t in zip(shape, nbytes_shape))
+    if not ok:
+        kind = "OrionHit" if getattr(np.dtype(np_dtype), "names", None) else np.dtype(np_dtype).name
+        where = "" if device is None or device < 0 else f" on cuda:{device}"
+        raise OrionError(f"{what}: expected a C-contiguous {kind} array of shape {shape}{where}, "
+                         f"got {type(x).__name__} {getattr(x, 'dtype', '?')} {nbytes_shape}")
+    return _ptr(x)
+
+
 def _settle(*tensors) -> None:
     """The library runs on streams of its own and its calls return when their work is done, but it
     knows nothing of the torch streams that may still be writing (or reading) the device buffers
@@ -152,6 +175,13 @@ class Scene:
     def __init__(self, model: host.Model, device: int = -1):
         L = lib()
         self.model = model
+        if device < 0:
+            try:
+                import torch
+                device = torch.cuda.current_device() if torch.cuda.is_available() else -1
+            except ImportError:
+                pass
+        self.device = device
         keep: List[np.ndarray] = []
         # one texture set (ambient, diffuse, specular, emissive) per material
         tex_descs, mat_descs = [], (_Material * max(1, len(model.materials)))()
@@ -200,27 +230,32 @@ class Scene:
         if _is_torch(org):
             import torch
             n = org.shape[0]
-            assert org.dtype == torch.float32 and dir.dtype == torch.float32 and org.is_contiguous() and dir.is_contiguous()
             if out is None:
                 out = torch.empty((n, 5), dtype=torch.int32, device=org.device)
+            po = _array_ptr(org, "closest_hit: org", (n, 3), "float32", np.float32, self.device)
+            pd = _array_ptr(dir, "closest_hit: dir", (n, 3), "float32", np.float32, self.device)
+            ph = _array_ptr(out, "closest_hit: out", (n, 5), "int32", np.int32, self.device)
             _settle(org)
-            _check(lib().orion_hip_closest_hit(self.h, org.data_ptr(), dir.data_ptr(), n, out.data_ptr()))
+            _check(lib().orion_hip_closest_hit(self.h, po, pd, n, ph))
             return out
         o = np.ascontiguousarray(org, np.float32).reshape(-1, 3); d = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
-        assert o.shape == d.shape
+        if o.shape != d.shape:
+            raise OrionError(f"closest_hit: {o.shape[0]} origins, {d.shape[0]} directions")
         if out is None:
             out = np.zeros(len(o), HIT_DTYPE)
-        _check(lib().orion_hip_closest_hit(self.h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data))
+        ph = _array_ptr(out, "closest_hit: out", (len(o),), "int32", HIT_DTYPE)
+        _check(lib().orion_hip_closest_hit(self.h, o.ctypes.data, d.ctypes.data, len(o), ph))
         return out
 
     def closest_hit_noalloc(self, org, dir, out):
         """orion_hip_closest_hit_noalloc: torch CUDA tensors only, the caller brings the output ([n, 5] int32)."""
         import torch
         n = org.shape[0]
-        assert org.dtype == torch.float32 and dir.dtype == torch.float32 and org.is_contiguous() and dir.is_contiguous()
-        assert out.dtype == torch.int32 and out.is_contiguous() and tuple(out.shape) == (n, 5)
+        po = _array_ptr(org, "closest_hit_noalloc: org", (n, 3), "float32", np.float32, self.device)
+        pd = _array_ptr(dir, "closest_hit_noalloc: dir", (n, 3), "float32", np.float32, self.device)
+        ph = _array_ptr(out, "closest_hit_noalloc: out", (n, 5), "int32", np.int32, self.device)
         _settle(org)
-        _check(lib().orion_hip_closest_hit_noalloc(self.h, org.data_ptr(), dir.data_ptr(), n, out.data_ptr()))
+        _check(lib().orion_hip_closest_hit_noalloc(self.h, po, pd, n, ph))
         return out
 
     def any_hit(self, org, dir, out=None):
@@ -229,13 +264,19 @@ class Scene:
             n = org.shape[0]
             if out is None:
                 out = torch.empty(n, dtype=torch.uint8, device=org.device)
+            po = _array_ptr(org, "any_hit: org", (n, 3), "float32", np.float32, self.device)
+            pd = _array_ptr(dir, "any_hit: dir", (n, 3), "float32", np.float32, self.device)
+            ph = _array_ptr(out, "any_hit: out", (n,), "uint8", np.uint8, self.device)
             _settle(org)
-            _check(lib().orion_hip_any_hit(self.h, org.data_ptr(), dir.data_ptr(), n, out.data_ptr()))
+            _check(lib().orion_hip_any_hit(self.h, po, pd, n, ph))
             return out
         o = np.ascontiguousarray(org, np.float32).reshape(-1, 3); d = np.ascontiguousarray(dir, np.float32).reshape(-1, 3)
+        if o.shape != d.shape:
+            raise OrionError(f"any_hit: {o.shape[0]} origins, {d.shape[0]} directions")
         if out is None:
             out = np.zeros(len(o), np.uint8)
-        _check(lib().orion_hip_any_hit(self.h, o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data))
+        ph = _array_ptr(out, "any_hit: out", (len(o),), "uint8", np.uint8)
+        _check(lib().orion_hip_any_hit(self.h, o.ctypes.data, d.ctypes.data, len(o), ph))
         return out
 
     # -- rendering --------------------------------------------------------------------
@@ -256,8 +297,9 @@ class Scene:
             p.tile_x0, p.tile_y0, p.tile_x1, p.tile_y1 = tile
         if accum is None:
             accum = np.zeros((height, width, 4), np.float32)
+        pa = _array_ptr(accum, "render: accum", (height, width, 4), "float32", np.float32, self.device)
         _settle(accum)
-        _check(lib().orion_hip_render(self.h, C.byref(cam), C.byref(p), _ptr(accum)))
+        _check(lib().orion_hip_render(self.h, C.byref(cam), C.byref(p), pa))
         return accum
 
     # -- profiling ----------------------------------------------------------------------

@@ -143,8 +143,6 @@ struct HitRec { float t, u, v; uint32_t gtri; };
 
 struct Light { float position[3]; float color[3]; float intensity; };
 
-constexpr int kMaxLights = 16;
-
 // Frame constants for the path-tracing kernels.
 struct FrameParams {
     float eye[3], front[3], right[3], up[3];
@@ -156,7 +154,7 @@ struct FrameParams {
     float inv_light_samples;   // 1.0f / light_samples (orion/raytracer.cpp:158)
     uint32_t seed_lo, seed_hi;
     uint32_t n_lights;
-    Light lights[kMaxLights];
+    const Light* lights;       // device memory, n_lights entries (any number: orion/raytracer.cpp:196 loops over a vector)
 };
 
 } // namespace orion_dev

@@ -363,8 +363,9 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 // and no register shuffling between loop levels.  The wave spends its time in
 // this loop, one instruction at a time, so its length is the traversal's speed.
 // `fast` (wave-uniform): slab_safe() holds for every active lane, the min/max
-// slab test may be used.  Preconditions: n_nodes > 0 and the scene's triangle array is below 4 GiB (the
-// walk is only chosen for scenes of a few dozen nodes).  SGPRs s52-s63 hold the
+// slab test may be used.  Preconditions: n_nodes > 0, and the node array and the triangle array are
+// each below 4 GiB (134 M nodes, 89 M triangles): positions are 32-bit byte offsets.  The scene upload
+// checks it and never selects this walk for a larger scene.  SGPRs s52-s63 hold the
 // node or triangle being processed.
 // ---------------------------------------------------------------------------
 #define ORION_WALK_BEFORE_DIV \

@@ -105,15 +105,20 @@ struct OrionScene {
     std::vector<void*> owned;         // device allocations of the flattened scene
     std::vector<uint32_t> mesh_tri_base;
     uint32_t n_nodes = 0, n_tris = 0;
+    // The hand-scheduled wave-synchronous walk steps through the node and triangle arrays with 32-bit byte
+    // offsets (intersect.h): scenes whose arrays reach 4 GiB never take it.
+    bool wave_ok = true;
     // options
     int traversal = 0;                // 0 auto, 1 lane, 2 wave, 3 one ray per wave at a time, 4 wide tree
     std::string wide_why_not;         // why the scene has no wide tree ("" if it has one)
     uint32_t tail_paths = 1u << 16;   // hand a batch's last paths to k_tail once this few are left
     uint64_t batch_paths = 64u << 20;     // paths in flight per batch (128 B of queues each)
     uint32_t overlap_below = 4u << 20;    // start the next batch on the other lane once this few rays are left (0: never)
+    uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
     DevBuf s_work;                    // grab counter + chunk list of the large-scene ray queries
+    DevBuf s_lights;                  // the point lights of the render call in progress
     uint32_t resident_blocks = 1280;  // blocks of the wide-walk query kernel the device holds at once
     Lane lane[2];                     // lane[0].stream == stream
     hipEvent_t ev_upload = nullptr;   // after the upload of a host accumulator
@@ -126,7 +131,7 @@ struct OrionScene {
 
     int mode() const {
         if (traversal == 1) return MODE_LANE;
-        if (traversal == 2) return MODE_WAVE;
+        if (traversal == 2 && wave_ok) return MODE_WAVE;
         if (traversal == 3) return MODE_EACH;
         if (traversal == 4) return MODE_WIDE;
         // The wave-synchronous walk costs the union of the lanes' paths (subtrees no lane enters
@@ -135,13 +140,13 @@ struct OrionScene {
         // beats the per-lane walk up to about 350 nodes, for cosine bounce rays up to about 400,
         // for rays in pixel order at every size (those take it anyway, see orion_hip_render).
         // Larger scenes: the ordered, distance-culled walk of the 4-wide tree where the scene has one.
-        if (n_nodes <= 384) return MODE_WAVE;
+        if (n_nodes <= 384 && wave_ok) return MODE_WAVE;
         return view.n_wide ? MODE_WIDE : MODE_LANE;
     }
     bool per_lane() const { const int m = mode(); return m == MODE_LANE || m == MODE_WIDE; }
     // Ray queries come in any order: on a large scene left to choose, each wave decides for itself.
     int query_mode() const {
-        if (traversal != 0 || !per_lane()) return mode();
+        if (traversal != 0 || !per_lane() || !wave_ok) return mode();
         return mode() == MODE_WIDE ? (int)MODE_ADAPT_WIDE : (int)MODE_ADAPT;
     }
 };
@@ -598,6 +603,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         v.dir_bound = (float)(bound * (1.0 - 1e-6));
     }
     s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
+    s->wave_ok = (uint64_t)tris.size() * sizeof(Tri) < (1ull << 32) && (uint64_t)nodes.size() * sizeof(Node) < (1ull << 32);
     {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0 &&
@@ -616,7 +622,7 @@ int orion_hip_scene_destroy(OrionScene* s) {
     drain_profile(s);
     for (hipEvent_t e : s->pool) (void)hipEventDestroy(e);
     for (void* p : s->owned) (void)hipFree(p);
-    s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release(); s->s_work.release();
+    s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release(); s->s_work.release(); s->s_lights.release();
     for (Lane& L : s->lane) {
         for (DevBuf& b : L.q) b.release();
         L.hits.release(); L.rad.release(); L.counter.release();
@@ -633,6 +639,7 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
     if (!s || !name) return fail(1, "set_option: null argument");
     if (!std::strcmp(name, "traversal")) {
         if (value < 0 || value > 4) return fail(1, "set_option: traversal must be 0, 1, 2, 3 or 4");
+        if (value == 2 && !s->wave_ok) return fail(1, "set_option: the scene's arrays reach 4 GiB, beyond the wave-synchronous walk's 32-bit offsets");
         if (value == 4 && s->view.n_wide == 0) return fail(1, "set_option: the scene has no wide tree (" + s->wide_why_not + ")");
         if (value == 3 && s->view.n_items == 0) return fail(1, "set_option: the scene is too large for one ray per wave (more than 64 inner nodes + triangles)");
         s->traversal = (int)value;
@@ -646,6 +653,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
     if (!std::strcmp(name, "overlap_below")) {
         if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: overlap_below out of range");
         s->overlap_below = (uint32_t)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "fail_at_bounce")) {
+        if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: fail_at_bounce out of range");
+        s->fail_at_bounce = (uint32_t)value;
         return 0;
     }
     if (!std::strcmp(name, "batch_paths")) {
@@ -724,7 +736,6 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     if (p->width == 0 || p->height == 0) return fail(1, "render: empty image");
     if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(1, "render: image too large");
     if (p->spp_end < p->spp_begin) return fail(1, "render: spp_end < spp_begin");
-    if (p->n_lights > (uint32_t)kMaxLights) return fail(1, "render: at most " + std::to_string(kMaxLights) + " point lights");
     if (p->n_lights && !p->lights) return fail(1, "render: lights is null");
     if (p->n_lights == 0 && p->light_samples == 0 && s->view.n_emissive) return fail(1, "render: light_samples must be >= 1");
     uint32_t x0 = p->tile_x0, y0 = p->tile_y0, x1 = p->tile_x1, y1 = p->tile_y1;
@@ -742,7 +753,12 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     F.inv_light_samples = 1.0f / (float)p->light_samples;
     F.seed_lo = (uint32_t)p->seed; F.seed_hi = (uint32_t)(p->seed >> 32);
     F.n_lights = p->n_lights;
-    for (uint32_t i = 0; i < p->n_lights; i++) std::memcpy(&F.lights[i], &p->lights[i], sizeof(Light));
+    static_assert(sizeof(Light) == sizeof(OrionLight), "light layouts must agree");
+    if (p->n_lights) {   // (a blocking copy of a few bytes: both lanes may read it from their first launch on)
+        if (int rc = s->s_lights.reserve((size_t)p->n_lights * sizeof(Light))) return rc;
+        HIP_TRY(hipMemcpy(s->s_lights.p, p->lights, (size_t)p->n_lights * sizeof(Light), hipMemcpyHostToDevice));
+    }
+    F.lights = static_cast<const Light*>(s->s_lights.p);
     const bool point = p->n_lights > 0;
 
     const uint64_t P = (uint64_t)F.tile_w * F.tile_h;
@@ -812,6 +828,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     };
     // Launches bounce `depth` of a batch: closest hits, then shading.
     auto bounce = [&](Batch& B, uint32_t depth) -> int {
+        if (s->fail_at_bounce && --s->fail_at_bounce == 0) return fail(3, "render: injected failure (option fail_at_bounce)");
         const uint32_t slot = depth % kRing, prev_slot = (depth + kRing - 1) % kRing;
         unsigned long long* cnt = B.count + 2 * slot;
         const unsigned long long* prev = depth ? B.count + 2 * prev_slot : nullptr;
@@ -827,7 +844,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         // wave-synchronous walk costs the union of its lanes' paths: the primary rays take it in
         // scenes of any size.  (The shadow rays a point-light frame casts from their hit points do
         // not: measured on the 38 k-node nanosuit frame, the per-lane walk is 25 % faster on those.)
-        const bool coherent = depth == 0 && per_lane && s->traversal == 0;
+        const bool coherent = depth == 0 && per_lane && s->traversal == 0 && s->wave_ok;
         with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
             if (depth == 0) {   // primary rays are generated inside the launch
@@ -860,53 +877,66 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         return 0;
     };
 
-    Batch cur, next;
-    bool next_begun = false;
-    Lane* last_resolve = nullptr;
-    for (uint64_t index = 0; index < n_batches; index++) {
-        if (next_begun) { cur = next; next_begun = false; }
-        else if (int rc = begin(cur, index)) return rc;
-        // Once this batch is down to its thin tail (launches that leave most of the chip idle), the
-        // next batch's first kLag bounces -- which need no counts from the host -- go to the other lane.
-        auto start_next = [&]() -> int {
-            if (next_begun || !two_lanes || index + 1 >= n_batches) return 0;
-            if (int rc = begin(next, index + 1)) return rc;
-            for (uint32_t d = 0; d < kLag && d <= p->max_depth; d++) if (int rc = bounce(next, d)) return rc;
-            next_begun = true;
-            return 0;
-        };
-        for (uint32_t depth = cur.launched; depth <= p->max_depth; depth++) {
-            if (int rc = bounce(cur, depth)) return rc;
-            if (depth >= kLag) {
-                if (int rc = consume(cur)) return rc;
-                if (cur.rays_in == 0) break;          // bounce `consumed` has no rays; the ones launched past it find none either
-                cur.bound = (uint32_t)cur.rays_in;
-                if (cur.bound < s->overlap_below) if (int rc = start_next()) return rc;
-                // Few paths left: one launch takes each of them to its end (one wave per path).  The
-                // rays it starts from are the ones the last shade launch emitted, at most `bound`.
-                if (tail_ok && cur.bound <= s->tail_paths && cur.launched <= p->max_depth) {
-                    launch_on(s, cur.L->stream, ORION_KERNEL_TAIL, cur.bound, point ? k_tail<true> : k_tail<false>, dim3((cur.bound + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
-                              s->view, cur.F, cur.launched, cur.qa, cur.count + 2 * ((cur.launched - 1) % kRing), cur.rad);
-                    HIP_TRY(hipGetLastError());
-                    break;
+    // The batches.  A failure anywhere in here (an allocation for the next batch, a launch) leaves launches of one
+    // or both lanes in flight: the caller below waits for them before it reports, so that the handle can be used again.
+    auto run = [&]() -> int {
+        Batch cur, next;
+        bool next_begun = false;
+        Lane* last_resolve = nullptr;
+        for (uint64_t index = 0; index < n_batches; index++) {
+            if (next_begun) { cur = next; next_begun = false; }
+            else if (int rc = begin(cur, index)) return rc;
+            // Once this batch is down to its thin tail (launches that leave most of the chip idle), the
+            // next batch's first kLag bounces -- which need no counts from the host -- go to the other lane.
+            auto start_next = [&]() -> int {
+                if (next_begun || !two_lanes || index + 1 >= n_batches) return 0;
+                if (int rc = begin(next, index + 1)) return rc;
+                for (uint32_t d = 0; d < kLag && d <= p->max_depth; d++) if (int rc = bounce(next, d)) return rc;
+                next_begun = true;
+                return 0;
+            };
+            for (uint32_t depth = cur.launched; depth <= p->max_depth; depth++) {
+                if (int rc = bounce(cur, depth)) return rc;
+                if (depth >= kLag) {
+                    if (int rc = consume(cur)) return rc;
+                    if (cur.rays_in == 0) break;          // bounce `consumed` has no rays; the ones launched past it find none either
+                    cur.bound = (uint32_t)cur.rays_in;
+                    if (cur.bound < s->overlap_below) if (int rc = start_next()) return rc;
+                    // Few paths left: one launch takes each of them to its end (one wave per path).  The
+                    // rays it starts from are the ones the last shade launch emitted, at most `bound`.
+                    if (tail_ok && cur.bound <= s->tail_paths && cur.launched <= p->max_depth) {
+                        launch_on(s, cur.L->stream, ORION_KERNEL_TAIL, cur.bound, point ? k_tail<true> : k_tail<false>, dim3((cur.bound + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
+                                  s->view, cur.F, cur.launched, cur.qa, cur.count + 2 * ((cur.launched - 1) % kRing), cur.rad);
+                        HIP_TRY(hipGetLastError());
+                        break;
+                    }
                 }
             }
+            if (s->profiling) {   // the statistics want every bounce; the last one has no extend launch after it
+                const uint32_t last = (cur.launched - 1) % kRing;
+                hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, cur.L->stream, cur.count + 2 * last, cur.L->h_count + 2 * last, cur.tags[last]);
+                while (cur.consumed < cur.launched) if (int rc = consume(cur)) return rc;
+            }
+            // The accumulator takes the batches' sums in ascending sample order, whichever lane they ran on.
+            if (last_resolve && last_resolve != cur.L) HIP_TRY(hipStreamWaitEvent(cur.L->stream, last_resolve->resolved, 0));
+            launch_on(s, cur.L->stream, ORION_KERNEL_RESOLVE, P, k_resolve, dim3(grid_for(P)), dim3(kBlock), cur.F, cur.rad, d_accum);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(cur.L->resolved, cur.L->stream));
+            last_resolve = cur.L;
         }
-        if (s->profiling) {   // the statistics want every bounce; the last one has no extend launch after it
-            const uint32_t last = (cur.launched - 1) % kRing;
-            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, cur.L->stream, cur.count + 2 * last, cur.L->h_count + 2 * last, cur.tags[last]);
-            while (cur.consumed < cur.launched) if (int rc = consume(cur)) return rc;
-        }
-        // The accumulator takes the batches' sums in ascending sample order, whichever lane they ran on.
-        if (last_resolve && last_resolve != cur.L) HIP_TRY(hipStreamWaitEvent(cur.L->stream, last_resolve->resolved, 0));
-        launch_on(s, cur.L->stream, ORION_KERNEL_RESOLVE, P, k_resolve, dim3(grid_for(P)), dim3(kBlock), cur.F, cur.rad, d_accum);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(cur.L->resolved, cur.L->stream));
-        last_resolve = cur.L;
+        if (!accum_dev) HIP_TRY(hipMemcpyAsync(accum_any, d_accum, img_bytes, hipMemcpyDeviceToHost, last_resolve->stream));
+        for (Lane& L : s->lane) HIP_TRY(hipStreamSynchronize(L.stream));
+        return 0;
+    };
+    const int rc = run();
+    if (rc != 0) {
+        const std::string why = g_error;
+        for (Lane& L : s->lane) (void)hipStreamSynchronize(L.stream);
+        (void)hipGetLastError();
+        if (s->profiling) drain_profile(s);
+        g_error = why;
     }
-    if (!accum_dev) HIP_TRY(hipMemcpyAsync(accum_any, d_accum, img_bytes, hipMemcpyDeviceToHost, last_resolve->stream));
-    for (Lane& L : s->lane) HIP_TRY(hipStreamSynchronize(L.stream));
-    return 0;
+    return rc;
 }
 
 int orion_hip_camera_vectors(const float eye[3], const float look_at[3], const float up[3],

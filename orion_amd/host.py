@@ -80,14 +80,19 @@ class Rtc:
 
 def parse_rtc(path: str) -> Rtc:
     raw = _Rtc()
-    lights = np.zeros((64, 7), np.float32)
-    lib().orion_host_parse_rtc(path.encode(), C.byref(raw), lights.ctypes.data, 64)
+    room = 64
+    lights = np.zeros((room, 7), np.float32)
+    lib().orion_host_parse_rtc(path.encode(), C.byref(raw), lights.ctypes.data, room)
+    if raw.n_lights > room:          # any number of L lines (orion/rtc_parser.cpp:120-127): read again with room for all
+        room = raw.n_lights
+        lights = np.zeros((room, 7), np.float32)
+        lib().orion_host_parse_rtc(path.encode(), C.byref(raw), lights.ctypes.data, room)
     return Rtc(obj_file=raw.obj_file.decode(), texture_file=raw.texture_file.decode(),
                recursion_level=raw.recursion_level, xres=raw.xres, yres=raw.yres,
                aspect_ratio=raw.aspect_ratio,
                view_point=np.array(raw.view_point[:], np.float32), look_at=np.array(raw.look_at[:], np.float32),
                vector_up=np.array(raw.vector_up[:], np.float32), y_view=raw.y_view,
-               lights=lights[:max(0, min(64, raw.n_lights))].copy())
+               lights=lights[:max(0, min(room, raw.n_lights))].copy())
 
 
 def write_rtc(path: str, rtc: Rtc) -> None:

@@ -1,6 +1,7 @@
 // Command-line front end with the reference's flags (orion/launcher.cpp:17-32):
 //   orion_rt <rtc_file> [-o|--output FILE] [-p SPP] [-l LIGHT_SAMPLES] [-t|--threads N]
 // plus --seed, --device and --bvh (split strategy of the host BVH build).  -t is accepted and ignored.
+// Exit status: 0, or non-zero when the arguments are wrong or the device could not render (no image is written then).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +43,5 @@ int main(int argc, char** argv) {
         else { std::printf("Unexpected argument %s\n", a.c_str()); usage(argv[0]); return 109; }
     }
     if (rtc_file.empty()) { std::printf("rtc_file is required\n"); usage(argv[0]); return 106; }
-    rt.traceRTC(rtc_file, output, samples, light_samples, threads);
-    return 0;
+    return rt.traceRTC(rtc_file, output, samples, light_samples, threads);
 }

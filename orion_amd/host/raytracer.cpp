@@ -122,8 +122,9 @@ bool load_ppm(const std::string& path, int& width, int& height, std::vector<uint
     return (size_t)f.gcount() == rgb.size();
 }
 
-void RayTracer::traceRTC(const std::string& rtc_file_name, const std::string& path_to_image,
-                         unsigned samples, unsigned light_samples, unsigned /*threads*/) {
+int RayTracer::traceRTC(const std::string& rtc_file_name, const std::string& path_to_image,
+                        unsigned samples, unsigned light_samples, unsigned /*threads*/) {
+    int status = 0;
     RtcData rtc = parse_rtc(rtc_file_name);
     width_ = std::max(0, rtc.xres); height_ = std::max(0, rtc.yres);
     image_.assign((size_t)width_ * height_ * 3, 0.0f);
@@ -167,6 +168,7 @@ void RayTracer::traceRTC(const std::string& rtc_file_name, const std::string& pa
         if (orion_hip_scene_create(meshes.data(), (uint32_t)meshes.size(), mats.data(), (uint32_t)mats.size(),
                                    pool.descs.data(), (uint32_t)pool.descs.size(), device, &scene) != 0) {
             std::printf("ERROR::ORION_HIP:: %s\n", orion_hip_last_error());
+            status = 2;
         } else {
             OrionCamera cam;
             orion_hip_camera_vectors(rtc.view_point, rtc.look_at, rtc.vector_up, rtc.y_view, rtc.aspect_ratio, &cam);
@@ -180,7 +182,10 @@ void RayTracer::traceRTC(const std::string& rtc_file_name, const std::string& pa
             p.seed = seed;
             p.n_lights = (uint32_t)lights.size(); p.lights = lights.data();
             std::vector<float> accum((size_t)width_ * height_ * 4, 0.0f);
-            if (orion_hip_render(scene, &cam, &p, accum.data()) != 0) std::printf("ERROR::ORION_HIP:: %s\n", orion_hip_last_error());
+            if (orion_hip_render(scene, &cam, &p, accum.data()) != 0) {
+                std::printf("ERROR::ORION_HIP:: %s\n", orion_hip_last_error());
+                status = 3;
+            }
             const float inv_samples = 1.0f / samples;
             for (size_t px = 0; px < (size_t)width_ * height_; px++)
                 for (int c = 0; c < 3; c++) image_[3 * px + c] = accum[4 * px + c] * inv_samples;
@@ -188,6 +193,10 @@ void RayTracer::traceRTC(const std::string& rtc_file_name, const std::string& pa
         }
     }
     std::printf("Triangles:                  %u\n", model.triangle_count());
+    if (status != 0) {   // the device did not render: no image is written (a zeroed one would pass for a result)
+        std::printf("ERROR::ORION_HIP:: rendering failed, %s not written\n", path_to_image.c_str());
+        return status;
+    }
 
     const std::string ext = extension_of(path_to_image);
     if (ext == ".ppm") savePPM(path_to_image);
@@ -197,6 +206,7 @@ void RayTracer::traceRTC(const std::string& rtc_file_name, const std::string& pa
         std::printf("Extension not recognized \"%s\" (will be saved as .hdr), supported extensions: .hdr .png .ppm\n", ext.c_str());
         saveHDR(path_to_image);
     }
+    return 0;
 }
 
 void RayTracer::savePPM(const std::string& path) const {

@@ -13,10 +13,11 @@ namespace orion_amd {
 
 class RayTracer {
 public:
-    // Same contract as the reference: void, errors are printed and rendering carries on with
-    // whatever loaded (an unreadable model gives a black image).  `threads` is accepted for
-    // command-line compatibility and ignored: the GPU needs no thread count.
-    void traceRTC(const std::string& rtc_file_name, const std::string& path_to_image,
+    // As the reference's: load errors are printed and rendering carries on with whatever loaded (an
+    // unreadable model gives a black image).  Unlike the reference's void function it returns a status:
+    // non-zero when the device could not create the scene (2) or render it (3); no image is written then.
+    // `threads` is accepted for command-line compatibility and ignored: the GPU needs no thread count.
+    int traceRTC(const std::string& rtc_file_name, const std::string& path_to_image,
                   unsigned samples, unsigned light_samples, unsigned threads);
 
     uint64_t seed = 1;   // key of the counter-based generator (the reference seeds from `this`)

@@ -118,6 +118,27 @@ def test_device_pointers_and_empty_batches(gpu):
     assert np.array_equal(one.view(np.uint32), want[:1].view(np.uint32))
 
 
+def test_binding_refuses_arrays_the_kernels_would_overrun(gpu):
+    """The library takes pointers on trust; the Python binding checks element type, contiguity, shape and
+    device before it hands them over."""
+    import torch
+    sc = scene_for(gpu, "cornell")
+    o = torch.zeros((100, 3), device="cuda"); d = torch.ones((100, 3), device="cuda")
+    for bad_o, bad_d, out in ((o.double(), d, None), (o, d[::2], None), (o, d.cpu(), None), (o.t(), d, None),
+                              (o, d, torch.zeros((50, 5), dtype=torch.int32, device="cuda")),
+                              (o, d, torch.zeros((100, 5), dtype=torch.float32, device="cuda"))):
+        with pytest.raises(gpu.OrionError, match="expected a C-contiguous"):
+            sc.closest_hit(bad_o, bad_d, out)
+    with pytest.raises(gpu.OrionError, match="expected a C-contiguous"):
+        sc.any_hit(o, d, torch.zeros(99, dtype=torch.uint8, device="cuda"))
+    cam = gpu.camera_vectors(*CORNELL_CAM[:3], CORNELL_CAM[3], 1.0)
+    for acc in (np.zeros((16, 16, 4), np.float64), np.zeros((16, 16, 3), np.float32), np.zeros((32, 16, 4), np.float32)[::2],
+                torch.zeros((8, 16, 4), device="cuda")):
+        with pytest.raises(gpu.OrionError, match="render: accum"):
+            sc.render(cam, 16, 16, 0, 1, 1, 1, accum=acc)
+    assert sc.render(cam, 16, 16, 0, 1, 1, 1, accum=torch.zeros((16, 16, 4), device="cuda"))[:, :, 3].min() == 1
+
+
 def test_scene_validation(gpu):
     import copy
     model = copy.deepcopy(conftest.load_model("cornell"))
@@ -278,10 +299,12 @@ def test_render_argument_validation(gpu):
         sc.render(cam, 8, 8, 2, 1, 1, 2)
     with pytest.raises(gpu.OrionError, match="tile"):
         sc.render(cam, 8, 8, 0, 1, 1, 2, tile=(0, 0, 9, 8))
-    with pytest.raises(gpu.OrionError, match="point lights"):
-        sc.render(cam, 8, 8, 0, 1, 1, 2, lights=np.zeros((17, 7), np.float32))
+    # any number of point lights, as in the reference (orion/raytracer.cpp:196 loops over a vector)
+    many = sc.render(cam, 8, 8, 0, 1, 1, 2, lights=np.tile(np.float32([[0, 1.5, 1.0, 0.5, 0.5, 0.5, 0.25]]), (40, 1)))
+    one = sc.render(cam, 8, 8, 0, 1, 1, 2, lights=np.float32([[0, 1.5, 1.0, 0.5, 0.5, 0.5, 10.0]]))
+    assert one[:, :, :3].max() > 0 and np.allclose(many, one, rtol=1e-4, atol=1e-6)
     with pytest.raises(gpu.OrionError, match="empty image"):
-        sc.render(cam, 0, 8, 0, 1, 1, 2, accum=np.zeros((8, 1, 4), np.float32))
+        sc.render(cam, 0, 8, 0, 1, 1, 2, accum=np.zeros((8, 0, 4), np.float32))
     # zero samples is a no-op, not an error
     acc = sc.render(cam, 8, 8, 3, 3, 1, 2)
     assert (acc == 0).all()
@@ -568,6 +591,28 @@ def test_quick_reciprocals_return_the_divisions_bits(gpu, name, modes):
             occ = sc.any_hit(o, d)
             assert np.array_equal(occ.astype(bool), oid[:, 0] != gpu.INVALID), f"{name} mode {mode} scale {sfac:g}: any hit"
     sc.set_option("traversal", 0)
+
+
+def test_a_failed_render_leaves_the_handle_usable(gpu):
+    """A render call that fails half way (the test hook makes the n-th bounce launch fail; an allocation for the
+    next batch failing ends the same way) has launches of one or both lanes in flight.  The call must wait for
+    them, report, and the next call on the same handle must give the bits of a fresh one."""
+    sc = gpu.Scene(conftest.load_model("cornell"), device=0)
+    eye, look, up, yv = CORNELL_CAM
+    W, H, spp = 256, 144, 12
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    ref = sc.render(cam, W, H, 0, spp, 2, 30, seed=21).copy()
+    sc.set_option("batch_paths", 3 * W * H)              # four batches, alternating between the two lanes
+    sc.set_option("overlap_below", 1 << 30)
+    sc.set_option("tail_paths", 0)                       # every bounce is a launch of its own: more places to fail
+    for n in (1, 2, 3, 5, 9, 14, 23):                    # first launch, the other lane's head, mid-batch, later batches
+        sc.set_option("fail_at_bounce", n)
+        with pytest.raises(gpu.OrionError, match="injected failure"):
+            sc.render(cam, W, H, 0, spp, 2, 30, seed=21)
+        sc.set_option("fail_at_bounce", 0)
+        img = sc.render(cam, W, H, 0, spp, 2, 30, seed=21)
+        assert np.array_equal(bits(ref), bits(img)), n
+    sc.close()
 
 
 def test_batching_and_repetition_change_nothing(gpu):
