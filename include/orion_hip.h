@@ -178,13 +178,16 @@ int orion_hip_profile_enable(OrionScene* scene, int enable);
 int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
 
 /* Tuning knobs, mainly for A/B measurements.  Known names:
- *   "traversal"   0 = choose per scene and per bounce (default: wave-synchronous for small
- *                 scenes and for the primary rays of any scene; ray queries on large scenes decide
- *                 per wave: rays leaving one point in nearly one direction walk together),
- *                 1 = per-lane traversal,
+ *   "traversal"   0 = choose per scene and per bounce (default: wave-synchronous for scenes of at
+ *                 most 384 nodes and for the primary rays of any scene, the ordered distance-culled
+ *                 walk of the 4-wide tree for everything else on larger scenes; ray queries on large
+ *                 scenes decide per 64 rays: rays leaving one point in nearly one direction walk together),
+ *                 1 = unculled per-lane traversal (the reference's visit order, node for node),
  *                 2 = wave-synchronous traversal (scene data through scalar loads),
  *                 3 = one ray per wave at a time (scenes of at most 64 inner nodes +
- *                 triangles; slow on batches, it exists to test the walk the tail kernel uses)
+ *                 triangles; slow on batches, it exists to test the walk the tail kernel uses),
+ *                 4 = ordered, distance-culled traversal of the 4-wide tree (scenes above 64 nodes whose
+ *                 trees keep every child box inside its parent's)
  *   "tail_paths"  a render batch hands its remaining paths to the one-path-per-wave
  *                 tail kernel once at most this many are left (0 = never; small scenes only)
  *   "batch_paths" upper bound on paths in flight per render batch
