@@ -194,6 +194,8 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *   "overlap_below" a render call of several batches starts the next batch on a second
  *                 stream (with queues of its own) once the current batch has fewer rays
  *                 than this left (default 4 Mi; 0 = one batch at a time, half the memory)
+ *   "draw_rays"   1 (default): on scenes that walk the 4-wide tree, the closest hits of bounce rays are found
+ *                 by waves that draw rays from the queue as their lanes finish; 0: four rays per thread
  *   "fail_at_bounce" test hook: the n-th bounce a render call launches from now on fails (once) with
  *                 code 3, whatever is in flight; the call waits for that work and the handle stays usable
  * Results never depend on these. */

@@ -57,6 +57,7 @@ struct EventPair { hipEvent_t a, b; int kernel; uint64_t items; };
 struct Lane {
     hipStream_t stream = nullptr;
     DevBuf q[6], hits, rad, counter;
+    DevBuf pre_hits, pre_work;               // large scenes: k_extend_wide's per-ray hits and its grab counter
     // Per-bounce counters travel to the host through a ring: the device slot of bounce d is
     // d % kRing; the next bounce's extend launch stores it into the pinned mirror
     // {tag << 32 | vertices, tag << 32 | rays}.
@@ -115,6 +116,7 @@ struct OrionScene {
     uint64_t batch_paths = 64u << 20;     // paths in flight per batch (128 B of queues each)
     uint32_t overlap_below = 4u << 20;    // start the next batch on the other lane once this few rays are left (0: never)
     uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
+    bool draw_rays = true;                // large scenes: bounce rays are handed to lanes as they finish (k_extend_wide)
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
     DevBuf s_work;                    // grab counter + chunk list of the large-scene ray queries
@@ -625,7 +627,7 @@ int orion_hip_scene_destroy(OrionScene* s) {
     s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release(); s->s_work.release(); s->s_lights.release();
     for (Lane& L : s->lane) {
         for (DevBuf& b : L.q) b.release();
-        L.hits.release(); L.rad.release(); L.counter.release();
+        L.hits.release(); L.rad.release(); L.counter.release(); L.pre_hits.release(); L.pre_work.release();
         if (L.h_count) (void)hipHostFree(L.h_count);
         if (L.resolved) (void)hipEventDestroy(L.resolved);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -653,6 +655,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
     if (!std::strcmp(name, "overlap_below")) {
         if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: overlap_below out of range");
         s->overlap_below = (uint32_t)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "draw_rays")) {
+        if (value < 0 || value > 1) return fail(1, "set_option: draw_rays must be 0 or 1");
+        s->draw_rays = value != 0;
         return 0;
     }
     if (!std::strcmp(name, "fail_at_bounce")) {
@@ -779,6 +786,8 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     }
     const int mode = s->mode();
     const bool per_lane = s->per_lane();
+    // Bounce rays of a large scene are handed to lanes as they finish (k_extend_wide) instead of 4 per thread.
+    const bool draw_rays = mode == MODE_WIDE && s->draw_rays;
     const bool tail_ok = s->view.n_items != 0 && !per_lane && s->tail_paths != 0;
     const uint64_t rays_per_vertex = point ? p->n_lights : (uint64_t)p->light_samples * s->view.n_emissive;
     const uint32_t n_bins = !per_lane ? (s->n_tris < kMaxBins ? (s->n_tris ? s->n_tris : 1u) : kMaxBins) : 1u;
@@ -810,6 +819,11 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         if (int rc = L.hits.reserve(max_paths * 16)) return rc;
         if (int rc = L.rad.reserve(max_paths * 16)) return rc;
         if (int rc = L.counter.reserve(kRing * 16)) return rc;
+        if (draw_rays) {
+            if (int rc = L.pre_hits.reserve(max_paths * 16)) return rc;
+            if (int rc = L.pre_work.reserve(16)) return rc;
+            HIP_TRY(hipMemsetAsync(L.pre_work.p, 0, 16, L.stream));
+        }
         B = Batch{};
         B.L = &L;
         B.F = F;
@@ -838,21 +852,30 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         const uint32_t tile = wide ? kTileWide : kBlock;
         auto extend = [&](auto kernel) {
             launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((B.bound + tile - 1) / tile), dim3(kBlock), s->view, B.F, B.rad, B.qa,
-                      prev, B.bound, B.qb, B.hits, cnt, clear, B.L->h_count + 2 * prev_slot, B.tags[prev_slot], n_bins);
+                      prev, B.bound, B.qb, B.hits, cnt, clear, B.L->h_count + 2 * prev_slot, B.tags[prev_slot], n_bins,
+                      static_cast<const float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p));
         };
-        // Rays of neighbouring pixels keep a wave together whatever the size of the tree, and the
-        // wave-synchronous walk costs the union of its lanes' paths: the primary rays take it in
-        // scenes of any size.  (The shadow rays a point-light frame casts from their hit points do
-        // not: measured on the 38 k-node nanosuit frame, the per-lane walk is 25 % faster on those.)
-        const bool coherent = depth == 0 && per_lane && s->traversal == 0 && s->wave_ok;
-        with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
-            constexpr int MODE = decltype(M)::value;
-            if (depth == 0) {   // primary rays are generated inside the launch
-                if (wide) extend(k_extend<MODE, kRaysWide, true>); else extend(k_extend<MODE, 1, true>);
-            } else {
-                if (wide) extend(k_extend<MODE, kRaysWide, false>); else extend(k_extend<MODE, 1, false>);
-            }
-        });
+        if (draw_rays && depth > 0) {
+            const uint32_t want = (B.bound + 2 * kQueryGrab - 1) / (2 * kQueryGrab);
+            const uint32_t grid = want < s->resident_blocks ? (want ? want : 1u) : s->resident_blocks;
+            launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, k_extend_wide, dim3(grid), dim3(kBlock), s->view, B.qa, prev, B.bound,
+                      static_cast<float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p));
+            if (wide) extend(k_extend<MODE_PRE, kRaysWide, false>); else extend(k_extend<MODE_PRE, 1, false>);
+        } else {
+            // Rays of neighbouring pixels keep a wave together whatever the size of the tree, and the
+            // wave-synchronous walk costs the union of its lanes' paths: the primary rays take it in
+            // scenes of any size.  (The shadow rays a point-light frame casts from their hit points do
+            // not: measured on the 38 k-node nanosuit frame, the per-lane walk is 25 % faster on those.)
+            const bool coherent = depth == 0 && per_lane && s->traversal == 0 && s->wave_ok;
+            with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
+                constexpr int MODE = decltype(M)::value;
+                if (depth == 0) {   // primary rays are generated inside the launch
+                    if (wide) extend(k_extend<MODE, kRaysWide, true>); else extend(k_extend<MODE, 1, true>);
+                } else {
+                    if (wide) extend(k_extend<MODE, kRaysWide, false>); else extend(k_extend<MODE, 1, false>);
+                }
+            });
+        }
         with_mode(mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
             auto shade = point ? k_shade<MODE, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf : k_shade<MODE, false>);

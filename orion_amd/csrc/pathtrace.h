@@ -34,7 +34,8 @@ static_assert(kBlock == kWideBlock, "the wide walk's stack is laid out for this 
 // that walk costs the union of the lanes' paths, which such rays keep small), else the per-lane walk.
 // MODE_WIDE: every lane walks the 4-wide tree, nearest first, with distance culling (wide_walk.h);
 // MODE_ADAPT_WIDE: MODE_ADAPT with that walk for the waves that are not coherent.
-enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4, MODE_WIDE = 5, MODE_ADAPT_WIDE = 6 };
+// MODE_PRE (k_extend only): the closest hits were found by k_extend_wide before the launch; k_extend just takes them.
+enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4, MODE_WIDE = 5, MODE_ADAPT_WIDE = 6, MODE_PRE = 7 };
 
 // True for every lane of a wave whose active rays share their origin exactly and lie within about
 // 25 degrees of the first active ray's direction.
@@ -203,10 +204,10 @@ __global__ __launch_bounds__(kBlock) void k_query_coherent(SceneView S, const fl
     if (threadIdx.x < s_nleft) chunks[s_base + threadIdx.x] = s_left[threadIdx.x];
 }
 
-template <bool ANY, bool LISTED>
-__global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float* __restrict__ org, const float* __restrict__ dir, uint32_t n,
-                                                       OrionHit* __restrict__ out, uint8_t* __restrict__ occ,
-                                                       uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks) {
+// The loop of a wave that draws rays: load(i, o, d) fetches ray i, store(i, h) takes its result.
+template <bool ANY, bool LISTED, typename Load, typename Store>
+__device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks,
+                                               Load load, Store store) {
     const uint32_t lane = lane_id(), tid = threadIdx.x;
     const uint32_t n_listed = LISTED ? work[1] : 0u;
     const uint32_t n_grabs = LISTED ? (n_listed + kQueryGrab / 64u - 1u) / (kQueryGrab / 64u) : (n + kQueryGrab - 1u) / kQueryGrab;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float*
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
                 const uint32_t i = g_next + rank;
                 if (idle && i < g_end) {
-                    o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i);
+                    load(i, o, d);
                     bool d_small, d_normal;
                     dir_class(d, S.dir_bound, d_small, d_normal);
                     quick_det = d_small;
@@ -273,8 +274,17 @@ __global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float*
             if (all_quick) wide_leaf_step<ANY, true>(S, o, d, h, w, tid);
             else wide_leaf_step<ANY, false>(S, o, d, h, w, tid);
         }
-        if (ray != kInvalid && w.cur == kWideEmpty && !slow) { query_store<ANY>(S, ray, h, out, occ); ray = kInvalid; }
+        if (ray != kInvalid && w.cur == kWideEmpty && !slow) { store(ray, h); ray = kInvalid; }
     }
+}
+
+template <bool ANY, bool LISTED>
+__global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float* __restrict__ org, const float* __restrict__ dir, uint32_t n,
+                                                       OrionHit* __restrict__ out, uint8_t* __restrict__ occ,
+                                                       uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks) {
+    wide_draw_rays<ANY, LISTED>(S, n, work, chunks,
+                                [&](uint32_t i, V3& o, V3& d) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); },
+                                [&](uint32_t i, const HitRec& h) { query_store<ANY>(S, i, h, out, occ); });
 }
 
 // --- path tracing --------------------------------------------------------------
@@ -388,6 +398,19 @@ __global__ void k_publish(const unsigned long long* cnt, unsigned long long* pub
     if (blockIdx.x == 0 && threadIdx.x == 0) publish_counters(cnt, publish, tag);
 }
 
+// The closest hits of a bounce's rays on a large scene, found the way the ray queries find theirs: the
+// waves of a launch that just fills the chip draw rays from the queue as their lanes finish
+// (wide_draw_rays).  Hits go to pre_hits[i], ray by ray; k_extend<MODE_PRE> then compacts them as it
+// compacts its own.  work[0]: the grab counter, zero at launch (k_extend<MODE_PRE> resets it).
+__global__ __launch_bounds__(kBlock) void k_extend_wide(SceneView S, Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
+                                                        float4* __restrict__ pre_hits, uint32_t* __restrict__ work) {
+    uint32_t n = n_bound;
+    if (prev) { const unsigned long long m = prev[1]; if (m < n) n = (uint32_t)m; }
+    wide_draw_rays<false, false>(S, n, work, nullptr,
+                                 [&](uint32_t i, V3& o, V3& d) { const float4 a = qin.o[i], b = qin.d[i]; o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); },
+                                 [&](uint32_t i, const HitRec& h) { pre_hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.gtri)); });
+}
+
 // GEN: the first bounce.  The rays are the primary rays, computed here from the path index
 // instead of being read from a queue (no generate pass, no 64 B/path round trip through HBM), and
 // every path's radiance slot is zeroed.
@@ -395,7 +418,8 @@ template <int MODE, uint32_t kRaysPerThread, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, float4* __restrict__ rad,
                                                    Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
                                                    Queues qout, HitRec* __restrict__ hits, unsigned long long* __restrict__ counter,
-                                                   unsigned long long* __restrict__ clear, unsigned long long* publish, uint32_t tag, uint32_t n_bins) {
+                                                   unsigned long long* __restrict__ clear, unsigned long long* publish, uint32_t tag, uint32_t n_bins,
+                                                   const float4* __restrict__ pre_hits, uint32_t* __restrict__ pre_work) {
     constexpr uint32_t kTile = kBlock * kRaysPerThread;   // rays per block
     __shared__ float4 s_hit[kTile];
     __shared__ uint16_t s_rank[kTile];
@@ -411,6 +435,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
         if (blockIdx.x != 0) return;
         if (threadIdx.x < 2) clear[threadIdx.x] = 0ull;
         if (prev && threadIdx.x == 0) publish_counters(prev, publish, tag);
+        if (MODE == MODE_PRE && threadIdx.x == 0) pre_work[0] = 0u;   // k_extend_wide's grab counter, for its next launch
     };
     if (tile0 >= n) { housekeeping(); return; }
     if (threadIdx.x < kMaxBins) s_cnt[threadIdx.x] = 0;
@@ -422,14 +447,18 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
         const uint32_t i = tile0 + slot;
         const bool active = i < n;
         V3 o = splat(0.0f), d = splat(1.0f);
-        if (active) {
+        if (active && MODE != MODE_PRE) {
             float4 a, b, c;
             if (GEN) primary_ray_tile(F, gen, i, slot, a, b, c);
             else { a = qin.o[i]; b = qin.d[i]; }
             o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
         }
         HitRec h = miss_rec();
-        traverse<MODE, false>(S, o, d, h, active);
+        if (MODE == MODE_PRE) {
+            if (active) { const float4 p = pre_hits[i]; h.t = p.x; h.u = p.y; h.v = p.z; h.gtri = __float_as_uint(p.w); }
+        } else {
+            traverse<MODE, false>(S, o, d, h, active);
+        }
         s_hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.gtri));
         if (h.gtri != kInvalid) {
             const uint32_t bin = min(h.gtri, n_bins - 1u);

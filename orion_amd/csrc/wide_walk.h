@@ -161,8 +161,17 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
     const uint32_t tid = threadIdx.x;
     WideState w; w.cur = 0u; w.sp = 0u; w.best_slot = 0u;
     bool ok = true;
-    while (w.cur != kWideEmpty) {
-        while (wide_at_node(w)) ok = wide_node_step(S, o, inv, h.t, w, tid) && ok;
+    // The lanes of the wave that walk do so together: node steps until nobody is at a node or kStaticQuorum lanes
+    // wait at a leaf (they would idle while the others walk on), then the leaves (nanosuit frame with four
+    // bounces: +13 % against "every lane to its next leaf first"; 8, 12 and 16 lanes within 2 % of each other).
+    constexpr uint32_t kStaticQuorum = 12;
+    while (__any(w.cur != kWideEmpty)) {
+        for (;;) {
+            const bool at_node = wide_at_node(w);
+            if (!__any(at_node)) break;
+            if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kStaticQuorum) break;
+            if (at_node) ok = wide_node_step(S, o, inv, h.t, w, tid) && ok;
+        }
         if (wide_at_leaf(w)) wide_leaf_step<ANY, QUICK>(S, o, d, h, w, tid);
     }
     return ok;

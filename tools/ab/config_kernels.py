@@ -10,8 +10,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from orion_amd import api  # noqa: E402
 
-for name, ls, spp in (("c3_nanosuit_fhd",1,32),("c4_hindu_4k",1,16)):
-    fr = api.load_frame(os.path.join(ROOT, "configs", name + ".rtc"), load_textures=False)
+for name, ls, spp in (("c3_nanosuit_fhd",1,32),("c3b_nanosuit_bounce_fhd",1,32),("c4_hindu_4k",1,16)):
+    fr = api.load_frame(os.path.join(ROOT, "configs", name + ".rtc"), load_textures=True)
     W, H = fr.rtc.xres, fr.rtc.yres
     sc = api.Scene(fr.model, device=0)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
