@@ -20,9 +20,10 @@
 //     slot whose grown box begins beyond the best hit so far.  The triangle test's rounding moves the
 //     computed hit by about 1e-5 / (sin(apex angle) * cos(angle to the normal)) of its distance, so the
 //     assumption can only fail for a ray within a fraction of a degree of the plane of a triangle that
-//     also lies behind the hit the ray does find; the CPU model of this walk and the unculled walk agree
-//     on every one of 10^8 rays aimed along and across two scenes' surfaces (tools/ab/stress_parity.py,
-//     tests/test_wide_tree.py).  Option "traversal" = 1 keeps the unculled per-lane walk.
+//     also lies behind the hit the ray does find.  That part is measured, not proven: this walk and the
+//     unculled walk agree on every one of 1.6 * 10^10 rays aimed along and across three scenes' surfaces
+//     (tools/ab/stress_wide.py), as does the CPU model of this walk with the reference's restatement
+//     (tests/test_wide_tree.py).  Option "traversal" = 1 keeps the unculled per-lane walk.
 //   * Rays the argument does not cover -- an origin component that is not finite or beyond the scene's
 //     bound, a direction component that is zero, denormal, not finite or outside 2^-40 .. 2^40 -- and
 //     lanes whose stack would overflow take the unculled walk (traverse_lane) instead.
