@@ -75,7 +75,7 @@ static_assert(kLag + kClearAhead + 1 < kRing, "a slot must be read before it is 
 // a buffer it allocates.  Every GPU the library runs on holds its own copy of this array until the process
 // ends; g_noalloc_scratch[device] is that copy's address, looked up once per device at scene creation.
 constexpr uint32_t kNoAllocMaxRays = 1u << 24;
-constexpr uint32_t kNoAllocWords = 64 + kNoAllocMaxRays / 64;     // 256 bytes of work words, then the chunk list (1 MiB)
+constexpr uint32_t kNoAllocWords = kWorkWords + kNoAllocMaxRays / 64;     // the work words, then the chunk list (1 MiB)
 constexpr int kMaxDevices = 64;
 uint32_t* g_noalloc_scratch[kMaxDevices] = {};
 std::mutex g_noalloc_mutex;
@@ -302,6 +302,18 @@ void with_query_mode(int mode, F&& f) {
     else with_mode(mode, f);
 }
 
+// How many rays a wave of the ray-drawing kernels takes at a time, and how many blocks to launch, for n rays:
+// about four grabs per wave, 64 to kQueryGrab rays each; no more blocks than the chip holds at once and
+// none without a grab for each of its waves.
+void draw_plan(const OrionScene* s, uint32_t n, uint32_t* grab, uint32_t* grid) {
+    const uint64_t waves = (uint64_t)s->resident_blocks * (kBlock / 64);
+    uint32_t chunks = (uint32_t)(n / (waves * 4 * 64));
+    chunks = chunks < 1 ? 1 : (chunks > kQueryGrab / 64 ? kQueryGrab / 64 : chunks);
+    *grab = chunks * 64;
+    const uint32_t want = (uint32_t)(((uint64_t)n + *grab * (kBlock / 64) - 1) / (*grab * (kBlock / 64)));
+    *grid = want < s->resident_blocks ? (want ? want : 1u) : s->resident_blocks;
+}
+
 // Ray queries on a large scene: the waves of a launch that just fills the chip draw rays from a global
 // counter (k_query_wide).  Left to choose, a first pass sends the 64-ray chunks that are coherent through the
 // wave-synchronous walk and lists the others.
@@ -310,23 +322,22 @@ int launch_query_wide(OrionScene* s, bool adapt, const float* d_org, const float
                       uint32_t* work, bool plain) {
     const int kid = ANY ? ORION_KERNEL_ANY_HIT : ORION_KERNEL_CLOSEST_HIT;
     const uint32_t n_chunks = (n + 63u) / 64u;
-    uint32_t* chunks = work + 64;   // 256 bytes of work words, then the list
-    HIP_TRY(hipMemsetAsync(work, 0, 16, s->stream));
-    // one block per kQueryGrab * 2 rays at most, and no more than the chip holds at once
-    const uint32_t want = (n + 2 * kQueryGrab - 1) / (2 * kQueryGrab);
-    const uint32_t grid = want < s->resident_blocks ? (want ? want : 1u) : s->resident_blocks;
+    uint32_t* chunks = work + kWorkWords;   // the work words, then the list
+    HIP_TRY(hipMemsetAsync(work, 0, kWorkWords * 4, s->stream));
+    uint32_t grab, grid;
+    draw_plan(s, n, &grab, &grid);
     const dim3 cgrid((n_chunks + kCoherentChunks - 1) / kCoherentChunks);
     if (plain) {   // no profiling events: nothing here may allocate
         if (adapt) {
             hipLaunchKernelGGL(k_query_coherent<ANY>, cgrid, dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_hits, d_occ, work, chunks);
-            hipLaunchKernelGGL((k_query_wide<ANY, true>), dim3(grid), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+            hipLaunchKernelGGL((k_query_wide<ANY, true>), dim3(grid), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_hits, d_occ, grab, work, (const uint32_t*)chunks);
         } else {
-            hipLaunchKernelGGL((k_query_wide<ANY, false>), dim3(grid), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+            hipLaunchKernelGGL((k_query_wide<ANY, false>), dim3(grid), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_hits, d_occ, grab, work, (const uint32_t*)chunks);
         }
     } else {
         if (adapt) launch(s, kid, 0, k_query_coherent<ANY>, cgrid, dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, chunks);
-        if (adapt) launch(s, kid, n, k_query_wide<ANY, true>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
-        else launch(s, kid, n, k_query_wide<ANY, false>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, work, (const uint32_t*)chunks);
+        if (adapt) launch(s, kid, n, k_query_wide<ANY, true>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, grab, work, (const uint32_t*)chunks);
+        else launch(s, kid, n, k_query_wide<ANY, false>, dim3(grid), dim3(kBlock), s->view, d_org, d_dir, n, d_hits, d_occ, grab, work, (const uint32_t*)chunks);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -334,7 +345,7 @@ int launch_query_wide(OrionScene* s, bool adapt, const float* d_org, const float
 
 // The scene's own work buffer for the wide ray queries (allocated on first use, grown as needed).
 int query_work(OrionScene* s, bool adapt, uint32_t n, uint32_t** work) {
-    if (int rc = s->s_work.reserve(256 + (adapt ? (size_t)((n + 63u) / 64u) * 4 : 0))) return rc;
+    if (int rc = s->s_work.reserve(kWorkWords * 4 + (adapt ? (size_t)((n + 63u) / 64u) * 4 : 0))) return rc;
     *work = static_cast<uint32_t*>(s->s_work.p);
     return 0;
 }
@@ -821,8 +832,8 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         if (int rc = L.counter.reserve(kRing * 16)) return rc;
         if (draw_rays) {
             if (int rc = L.pre_hits.reserve(max_paths * 16)) return rc;
-            if (int rc = L.pre_work.reserve(16)) return rc;
-            HIP_TRY(hipMemsetAsync(L.pre_work.p, 0, 16, L.stream));
+            if (int rc = L.pre_work.reserve(kWorkWords * 4)) return rc;
+            HIP_TRY(hipMemsetAsync(L.pre_work.p, 0, kWorkWords * 4, L.stream));
         }
         B = Batch{};
         B.L = &L;
@@ -856,10 +867,10 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                       static_cast<const float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p));
         };
         if (draw_rays && depth > 0) {
-            const uint32_t want = (B.bound + 2 * kQueryGrab - 1) / (2 * kQueryGrab);
-            const uint32_t grid = want < s->resident_blocks ? (want ? want : 1u) : s->resident_blocks;
+            uint32_t grab, grid;
+            draw_plan(s, B.bound, &grab, &grid);
             launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, k_extend_wide, dim3(grid), dim3(kBlock), s->view, B.qa, prev, B.bound,
-                      static_cast<float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p));
+                      static_cast<float4*>(B.L->pre_hits.p), grab, static_cast<uint32_t*>(B.L->pre_work.p));
             if (wide) extend(k_extend<MODE_PRE, kRaysWide, false>); else extend(k_extend<MODE_PRE, 1, false>);
         } else {
             // Rays of neighbouring pixels keep a wave together whatever the size of the tree, and the

@@ -140,10 +140,13 @@ __global__ __launch_bounds__(kBlock) void k_anyhit_api(SceneView S, const float*
 // The ray queries of large scenes (MODE_WIDE, MODE_ADAPT_WIDE).  Incoherent rays take wildly different
 // numbers of steps through the tree (half of them a handful, one in a hundred over a hundred), and a wave
 // that holds 64 rays from start to end runs as long as its longest one with most lanes idle.  Here the
-// waves of a launch that just fills the chip draw rays until none are left: a wave takes kQueryGrab
-// consecutive rays at a time from a global counter (one atomic per grab) and hands them to its lanes as
+// waves of a launch that just fills the chip draw rays until none are left: a wave takes `grab`
+// consecutive rays at a time (64 to kQueryGrab, by the size of the batch) from a global counter (one atomic per grab) and hands them to its lanes as
 // they finish, kRefillMin lanes at a time.
-//   work[0]: the grab counter (zero at launch), work[1]: number of listed chunks (LISTED only).
+//   work[1]: number of listed chunks (LISTED only); work[kWorkCounters + 16 p]: the grab counter of partition p
+//   (all zero at launch).  The grabs are split into kWorkParts equal ranges with a counter each, 64 bytes
+//   apart: a wave starts on the range of its block and moves on to the next when that one is used up.  (One
+//   counter for all serialises at the memory side, ~12 ns per grab: batches of short rays were bound by it.)
 // LISTED (MODE_ADAPT_WIDE): k_query_coherent has been over the batch first; 64-ray chunks whose rays leave
 // one point in nearly one direction (camera rays) went through the wave-synchronous walk there, and the
 // others are listed in `chunks` -- a grab is then one listed chunk.
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(kBlock) void k_anyhit_api(SceneView S, const float*
 #endif
 constexpr uint32_t kRefillMin = ORION_REFILL_MIN;       // lanes out of work before a wave fetches
 constexpr uint32_t kLeafQuorumWide = ORION_LEAF_QUORUM; // lanes waiting at a leaf before the wave turns to the triangles
-constexpr uint32_t kQueryGrab = ORION_QUERY_GRAB;       // rays a wave takes from the global counter at a time
+constexpr uint32_t kQueryGrab = ORION_QUERY_GRAB;       // most rays a wave takes from the global counter at a time
+constexpr uint32_t kWorkParts = 16, kWorkCounters = 64, kWorkWords = kWorkCounters + 16 * kWorkParts;   // layout of the work words
 constexpr uint32_t kCoherentChunks = 16;                // 64-ray chunks per block of k_query_coherent
 
 template <bool ANY>
@@ -206,11 +210,13 @@ __global__ __launch_bounds__(kBlock) void k_query_coherent(SceneView S, const fl
 
 // The loop of a wave that draws rays: load(i, o, d) fetches ray i, store(i, h) takes its result.
 template <bool ANY, bool LISTED, typename Load, typename Store>
-__device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks,
+__device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, uint32_t grab, uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks,
                                                Load load, Store store) {
     const uint32_t lane = lane_id(), tid = threadIdx.x;
     const uint32_t n_listed = LISTED ? work[1] : 0u;
-    const uint32_t n_grabs = LISTED ? (n_listed + kQueryGrab / 64u - 1u) / (kQueryGrab / 64u) : (n + kQueryGrab - 1u) / kQueryGrab;
+    const uint32_t n_grabs = LISTED ? (n_listed + grab / 64u - 1u) / (grab / 64u) : (n + grab - 1u) / grab;
+    const uint32_t part_grabs = (n_grabs + kWorkParts - 1u) / kWorkParts;   // grabs per partition
+    uint32_t part = blockIdx.x % kWorkParts, parts_done = 0u;                // (wave-uniform)
     uint32_t g_next = 0u, g_end = 0u;    // the rays of the wave's current grab not handed out yet (wave-uniform)
     uint32_t l_next = 0u, l_end = 0u;    // LISTED: the listed chunks of the grab not started yet
     bool pool_empty = false;             // (wave-uniform)
@@ -226,12 +232,17 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
         const uint64_t busy = ~mi & __ballot(true);
         if (!pool_empty && mi != 0ull && ((uint32_t)__popcll(mi) >= kRefillMin || busy == 0ull)) {
             if (g_next == g_end && l_next == l_end) {   // a new grab
-                uint32_t g = 0u;
-                if (lane == 0u) g = atomicAdd(&work[0], 1u);
-                g = __builtin_amdgcn_readfirstlane(g);
+                uint32_t g = n_grabs;
+                while (parts_done < kWorkParts) {
+                    uint32_t k = 0u;
+                    if (lane == 0u) k = atomicAdd(&work[kWorkCounters + 16u * part], 1u);
+                    k = __builtin_amdgcn_readfirstlane(k);
+                    if (k < part_grabs && part * part_grabs + k < n_grabs) { g = part * part_grabs + k; break; }
+                    part = (part + 1u) % kWorkParts; parts_done++;   // this range is used up: on to the next
+                }
                 if (g >= n_grabs) pool_empty = true;
-                else if (LISTED) { l_next = g * (kQueryGrab / 64u); l_end = min(n_listed, l_next + kQueryGrab / 64u); }
-                else { g_next = g * kQueryGrab; g_end = min(n, g_next + kQueryGrab); }
+                else if (LISTED) { l_next = g * (grab / 64u); l_end = min(n_listed, l_next + grab / 64u); }
+                else { g_next = g * grab; g_end = min(n, g_next + grab); }
             }
             if (LISTED && g_next == g_end && l_next != l_end) { g_next = chunks[l_next] * 64u; g_end = min(n, g_next + 64u); l_next++; }
             if (!pool_empty) {
@@ -281,8 +292,8 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
 template <bool ANY, bool LISTED>
 __global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float* __restrict__ org, const float* __restrict__ dir, uint32_t n,
                                                        OrionHit* __restrict__ out, uint8_t* __restrict__ occ,
-                                                       uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks) {
-    wide_draw_rays<ANY, LISTED>(S, n, work, chunks,
+                                                       uint32_t grab, uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks) {
+    wide_draw_rays<ANY, LISTED>(S, n, grab, work, chunks,
                                 [&](uint32_t i, V3& o, V3& d) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); },
                                 [&](uint32_t i, const HitRec& h) { query_store<ANY>(S, i, h, out, occ); });
 }
@@ -401,12 +412,12 @@ __global__ void k_publish(const unsigned long long* cnt, unsigned long long* pub
 // The closest hits of a bounce's rays on a large scene, found the way the ray queries find theirs: the
 // waves of a launch that just fills the chip draw rays from the queue as their lanes finish
 // (wide_draw_rays).  Hits go to pre_hits[i], ray by ray; k_extend<MODE_PRE> then compacts them as it
-// compacts its own.  work[0]: the grab counter, zero at launch (k_extend<MODE_PRE> resets it).
+// compacts its own.  work: the grab counters, zero at launch (k_extend<MODE_PRE> resets them).
 __global__ __launch_bounds__(kBlock) void k_extend_wide(SceneView S, Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
-                                                        float4* __restrict__ pre_hits, uint32_t* __restrict__ work) {
+                                                        float4* __restrict__ pre_hits, uint32_t grab, uint32_t* __restrict__ work) {
     uint32_t n = n_bound;
     if (prev) { const unsigned long long m = prev[1]; if (m < n) n = (uint32_t)m; }
-    wide_draw_rays<false, false>(S, n, work, nullptr,
+    wide_draw_rays<false, false>(S, n, grab, work, nullptr,
                                  [&](uint32_t i, V3& o, V3& d) { const float4 a = qin.o[i], b = qin.d[i]; o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); },
                                  [&](uint32_t i, const HitRec& h) { pre_hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.gtri)); });
 }
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
         if (blockIdx.x != 0) return;
         if (threadIdx.x < 2) clear[threadIdx.x] = 0ull;
         if (prev && threadIdx.x == 0) publish_counters(prev, publish, tag);
-        if (MODE == MODE_PRE && threadIdx.x == 0) pre_work[0] = 0u;   // k_extend_wide's grab counter, for its next launch
+        if (MODE == MODE_PRE && threadIdx.x < kWorkParts) pre_work[kWorkCounters + 16u * threadIdx.x] = 0u;   // k_extend_wide's grab counters, for its next launch
     };
     if (tile0 >= n) { housekeeping(); return; }
     if (threadIdx.x < kMaxBins) s_cnt[threadIdx.x] = 0;
