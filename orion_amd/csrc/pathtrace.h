@@ -208,6 +208,98 @@ __global__ __launch_bounds__(kBlock) void k_query_coherent(SceneView S, const fl
     if (threadIdx.x < s_nleft) chunks[s_base + threadIdx.x] = s_left[threadIdx.x];
 }
 
+// --- sharing a ray between lanes ------------------------------------------------
+// Once a wave's pool of rays is used up its lanes finish one by one, and the wave lives as long as its
+// longest ray: hundreds of node steps taken one after the other by one lane while the rest sit idle.  From
+// then on a free lane takes the top entry of a busy lane's stack together with a copy of the ray and of its
+// best hit so far, walks that subtree on a stack of its own (it may hand parts on in turn), and gives its best
+// hit back when it is done.  The owner keeps the better of the two by the walk's result rule ("smaller t, or
+// equal t and the later triangle slot"), which does not depend on the order of visits, so the ray's result is
+// what one lane alone would have found; a taker only lacks the owner's later improvements of `best`, which
+// costs it visits the owner would have culled, never a result.
+#ifndef ORION_WIDE_SHARE
+#define ORION_WIDE_SHARE 1
+#endif
+constexpr uint32_t kNoOwner = 64u;
+#ifndef ORION_SHARE_MIN
+#define ORION_SHARE_MIN 16
+#endif
+constexpr uint32_t kShareMin = ORION_SHARE_MIN;      // free lanes it takes to make a round of handing out worthwhile
+static_assert(kWideStack >= 13, "a handed-over part travels through the taker's (empty) stack column: 13 words");
+__shared__ uint8_t g_wide_taker[kWideBlock];
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Free lanes take parts from lanes that have something stacked.  Returns whether free lanes remain or were
+// served (the caller then gives the busy lanes a chance to stack something after every node step).
+__device__ __forceinline__ bool wide_share(WideState& w, V3& o, V3& d, V3& inv, HitRec& h, bool& quick_det, bool slow, bool idle,
+                                           uint32_t& owner, uint32_t& lent) {
+    const uint32_t lane = lane_id(), tid = threadIdx.x, wave0 = tid & ~63u;
+    const bool give = w.cur != kWideEmpty && !slow && w.sp != 0u;
+    const uint64_t mt = __ballot(idle), mg = __ballot(give);
+    if ((uint32_t)__popcll(mt) < kShareMin) return false;
+    if (mg == 0ull) return true;
+    const uint32_t n = min((uint32_t)__popcll(mt), (uint32_t)__popcll(mg));
+    const uint32_t rank_t = __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u));
+    const uint32_t rank_g = __builtin_amdgcn_mbcnt_hi((uint32_t)(mg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg, 0u));
+    const bool takes = idle && rank_t < n, gives = give && rank_g < n;
+    if (takes) g_wide_taker[wave0 + rank_t] = (uint8_t)lane;
+    wave_lds_fence();
+    if (gives) {
+        const uint32_t col = wave0 + g_wide_taker[wave0 + rank_g];   // the taker's stack column: empty, it carries the part
+        w.sp--;
+        const uint32_t ref = g_wide_ref[w.sp][tid], tb = g_wide_t[w.sp][tid];
+        g_wide_ref[0][col] = __float_as_uint(o.x); g_wide_ref[1][col] = __float_as_uint(o.y); g_wide_ref[2][col] = __float_as_uint(o.z);
+        g_wide_ref[3][col] = __float_as_uint(d.x); g_wide_ref[4][col] = __float_as_uint(d.y); g_wide_ref[5][col] = __float_as_uint(d.z);
+        g_wide_ref[6][col] = __float_as_uint(h.t); g_wide_ref[7][col] = __float_as_uint(h.u); g_wide_ref[8][col] = __float_as_uint(h.v);
+        g_wide_ref[9][col] = h.gtri; g_wide_ref[10][col] = w.best_slot; g_wide_ref[11][col] = ref;
+        g_wide_ref[12][col] = tb | (quick_det ? 1u << 16 : 0u) | lane << 17;
+        lent++;
+    }
+    wave_lds_fence();
+    if (takes) {
+        o = mk(__uint_as_float(g_wide_ref[0][tid]), __uint_as_float(g_wide_ref[1][tid]), __uint_as_float(g_wide_ref[2][tid]));
+        d = mk(__uint_as_float(g_wide_ref[3][tid]), __uint_as_float(g_wide_ref[4][tid]), __uint_as_float(g_wide_ref[5][tid]));
+        h.t = __uint_as_float(g_wide_ref[6][tid]); h.u = __uint_as_float(g_wide_ref[7][tid]); h.v = __uint_as_float(g_wide_ref[8][tid]);
+        h.gtri = g_wide_ref[9][tid]; w.best_slot = g_wide_ref[10][tid];
+        const uint32_t ref = g_wide_ref[11][tid], x = g_wide_ref[12][tid];
+        inv = ray_inverse(d);
+        quick_det = (x >> 16 & 1u) != 0u;
+        owner = x >> 17;
+        w.sp = 0u;
+        w.cur = __uint_as_float((x & 0xFFFFu) << 16) > h.t ? kWideEmpty : ref;   // (culled by now: given back at once)
+    }
+    wave_lds_fence();   // the columns are stacks again
+    return true;
+}
+
+// Lanes that are done with a part give their best hit to the part's owner.
+__device__ __forceinline__ void wide_deliver(WideState& w, HitRec& h, bool slow, uint32_t& owner, uint32_t& lent) {
+    const uint32_t lane = lane_id();
+    for (;;) {
+        uint64_t m = __ballot(owner != kNoOwner && w.cur == kWideEmpty && !slow && lent == 0u);
+        if (m == 0ull) break;
+        while (m) {
+            const uint32_t from = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint32_t to = __builtin_amdgcn_readlane(owner, from);
+            const float t = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.t), from));
+            const float u = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.u), from));
+            const float v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h.v), from));
+            const uint32_t gtri = __builtin_amdgcn_readlane(h.gtri, from), slot = __builtin_amdgcn_readlane(w.best_slot, from);
+            if (lane == to) {
+                if (gtri != kInvalid && (t < h.t || (t == h.t && slot > w.best_slot))) { h.t = t; h.u = u; h.v = v; h.gtri = gtri; w.best_slot = slot; }
+                lent--;
+            }
+            if (lane == from) owner = kNoOwner;
+        }
+    }
+}
+
 // The loop of a wave that draws rays: load(i, o, d) fetches ray i, store(i, h) takes its result.
 template <bool ANY, bool LISTED, typename Load, typename Store>
 __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, uint32_t grab, uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks,
@@ -226,8 +318,14 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
     HitRec h = miss_rec();
     WideState w; w.cur = kWideEmpty; w.sp = 0u; w.best_slot = 0u;
     bool quick_det = false, slow = false;
+    // Sharing (see wide_share): the lane whose ray this lane walks a part of, and how many lanes walk parts of this lane's.
+    uint32_t owner = kNoOwner, lent = 0u;
     for (;;) {
-        const bool idle = w.cur == kWideEmpty && !slow;
+#if ORION_WIDE_SHARE
+        if (pool_empty) wide_deliver(w, h, slow, owner, lent);
+#endif
+        if (ray != kInvalid && w.cur == kWideEmpty && !slow && lent == 0u) { store(ray, h); ray = kInvalid; }
+        const bool idle = w.cur == kWideEmpty && !slow && ray == kInvalid && owner == kNoOwner;
         const uint64_t mi = __ballot(idle);
         const uint64_t busy = ~mi & __ballot(true);
         if (!pool_empty && mi != 0ull && ((uint32_t)__popcll(mi) >= kRefillMin || busy == 0ull)) {
@@ -262,13 +360,20 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
                 g_next = min(g_end, g_next + (uint32_t)__popcll(mi));
             }
         }
+        bool sharing = false;   // (wave-uniform) lanes are free to take parts of other lanes' rays
+#if ORION_WIDE_SHARE
+        if (pool_empty) sharing = wide_share(w, o, d, inv, h, quick_det, slow, idle, owner, lent);
+#endif
         if (__ballot(w.cur != kWideEmpty || slow) == 0ull) {
-            if (pool_empty) break;
+            if (pool_empty && __ballot(ray != kInvalid || owner != kNoOwner) == 0ull) break;
             continue;
         }
         // rays the wide walk does not take, and lanes whose stack overflowed: the unculled walk
         if (__any(slow)) {
-            if (slow) { h = miss_rec(); traverse_lane<ANY>(S, o, d, h); slow = false; w.cur = kWideEmpty; }
+            if (slow) {
+                h = miss_rec(); traverse_lane<ANY>(S, o, d, h); slow = false; w.cur = kWideEmpty;
+                w.best_slot = h.gtri != kInvalid ? S.slot_of[h.gtri] : 0u;   // (the result rule of shared rays compares slots)
+            }
         }
         // Node steps until nobody is at a node -- or until enough lanes wait at a leaf, or enough have run
         // out of work to make fetching worthwhile: they would sit idle while the others walk on.
@@ -278,6 +383,7 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kLeafQuorumWide) break;
             if (!pool_empty && (uint32_t)__popcll(__ballot(w.cur == kWideEmpty && !slow)) >= kRefillMin) break;
             if (at_node && !wide_node_step(S, o, inv, h.t, w, tid)) slow = true;
+            if (sharing && __any(w.sp != 0u && w.cur != kWideEmpty)) break;   // somebody has a part to hand out
         }
         const bool at_leaf = wide_at_leaf(w);
         const bool all_quick = __all(!at_leaf || quick_det);
@@ -285,7 +391,6 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
             if (all_quick) wide_leaf_step<ANY, true>(S, o, d, h, w, tid);
             else wide_leaf_step<ANY, false>(S, o, d, h, w, tid);
         }
-        if (ray != kInvalid && w.cur == kWideEmpty && !slow) { store(ray, h); ray = kInvalid; }
     }
 }
 

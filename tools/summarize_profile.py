@@ -31,6 +31,20 @@ def main():
             d = json.load(open(b))
             lines.append(f"\nbench.py under the profiler: {d['value'] / 1e9:.3f} Gsamples/s, HIP-event kernel totals: " +
                          ", ".join(f"{k} {v['ms']:.3f} ms / {v['launches']} launches" for k, v in d.get("kernels", {}).items()))
+            # bench.py's roofline comes from its profiled pass, the last launches of the run (one batch at a time, no
+            # overlap between the two lanes): the profiler's durations of those same launches, for comparison.
+            kt = glob.glob(prefix + "trace/**/*kernel_trace.csv", recursive=True)
+            if kt:
+                spans = collections.defaultdict(list)
+                for r in csv.DictReader(open(kt[0])):
+                    k = kname(r["Kernel_Name"])
+                    if k:
+                        spans[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+                for k, v in d.get("kernels", {}).items():
+                    last = [x[1] for x in sorted(spans.get(k, []))[-v["launches"]:]]
+                    if len(last) == v["launches"]:
+                        lines.append(f"- {k}: the profiled pass's {len(last)} launches average {sum(last) / len(last) / 1e3:.1f} us in the profiler's trace, "
+                                     f"{v['avg_launch_ms'] * 1e3:.1f} us by bench.py's HIP events")
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.Counter()
     for f in glob.glob(prefix + "pmc*/**/*counter_collection.csv", recursive=True):
