@@ -103,21 +103,18 @@ bool walk(const Model& M, V3 o, V3 d, bool cull, float kappa, Best& best, Stats&
             Entry hit[4]; int nh = 0;
             if (in) {
                 const uint32_t refs[4] = {n.ref0, n.ref1, n.ref2, n.ref3};
-                float origin[3], cell[3], reach = 0.0f;
+                float reach = 0.0f;
                 const float oo[3] = {o.x, o.y, o.z};
-                for (int a = 0; a < 3; a++) {
-                    origin[a] = orion_wide::grid_origin(n.lo[a], pad); cell[a] = orion_wide::grid_cell(n.lo[a], n.hi[a], pad);
-                    const float far_end = orion_wide::grid_decode(255u, cell[a], origin[a]);
-                    reach = std::fmax(reach, std::fmax(std::fabs(origin[a] - oo[a]), std::fabs(far_end - oo[a])));
-                }
-                // grow every slot box by kappa times the origin's distance to the farthest corner of the node's grid
-                const float r = kappa * reach;
+                for (int a = 0; a < 3; a++) reach = std::fmax(reach, std::fmax(std::fabs(n.lo[a] - oo[a]), std::fabs(n.hi[a] - oo[a])));
+                // grow every decoded slot box by the pad and by kappa times (the origin's distance to the farthest
+                // corner of the node's box + two pads)
+                const float r = pad + kappa * (reach + 2.0f * pad);
                 for (int k = 0; k < 4; k++) {
                     if (refs[k] == orion_dev::kWideEmpty) continue;
                     float lo[3], hi[3];
                     for (int a = 0; a < 3; a++) {
-                        lo[a] = orion_wide::grid_decode((n.qlo[a] >> (8 * k)) & 0xFFu, cell[a], origin[a]) - r;
-                        hi[a] = orion_wide::grid_decode((n.qhi[a] >> (8 * k)) & 0xFFu, cell[a], origin[a]) + r;
+                        lo[a] = (float)orion_wide::grid_decode((n.qlo[a] >> (8 * k)) & 0xFFu, n.lo[a], n.hi[a]) - r;
+                        hi[a] = (float)orion_wide::grid_decode((n.qhi[a] >> (8 * k)) & 0xFFu, n.lo[a], n.hi[a]) + r;
                     }
                     float a, b;
                     slab(lo, hi, o, inv, a, b);

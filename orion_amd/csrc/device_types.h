@@ -74,10 +74,10 @@ static_assert(sizeof(WaveItem) == 64, "WaveItem layout");
 //     the box for rays without NaN products, so they need no test of their own.
 //   * A leaf is only ever a slot of the wide node that stands for its binary parent (an inner node
 //     with a leaf child is never collapsed away): entering that wide node is the leaf's condition.
-//   * The four slots carry their boxes as bytes on a grid spanned by the node's own box grown by
-//     the scene's pad on every side (decoded: byte * cell + origin); a decoded box contains the
-//     slot's real box grown by the pad.  These boxes only ever REJECT: a slot is skipped when the
-//     ray misses its decoded box or meets it beyond the best hit so far.
+//   * The four slots carry their boxes as bytes on a grid over the node's own box (254 cells from `lo` to
+//     `hi` per axis); a decoded box, grown by the scene's pad, contains the slot's real box grown by
+//     three quarters of the pad.  These boxes only ever REJECT: a slot is skipped when the ray misses
+//     its decoded box (grown by the pad and the walk's slack) or meets it beyond the best hit so far.
 //   * ref: kWideEmpty, the index of a wide node, or kWideLeaf | count << 25 | first triangle slot.
 // Virtual nodes tie the meshes' roots together; their box is the union of what hangs below, grown
 // by more than any slack the walk applies, so that missing it means missing everything below.
@@ -92,10 +92,10 @@ static_assert(sizeof(WideNode) == 64, "WideNode layout");
 constexpr uint32_t kWideEmpty = 0x7FFFFFFFu;   // also "nothing left to visit" in the walk
 constexpr uint32_t kWideLeaf = 0x80000000u;
 constexpr uint32_t kWideMaxLeaf = 63;
-// The walk grows every decoded box by this fraction of the ray origin's distance to the farthest
-// corner of the node's grid (wide_walk.h explains what the slack is for).
+// The walk grows every decoded box by the pad and by this fraction of (the ray origin's distance to the
+// farthest corner of the node's box + two pads) (wide_walk.h explains what the slack is for).
 constexpr float kWideSlack = 0x1p-7f;
-constexpr float kWideInvCells = 1.0f / 254.0f;   // the byte grid spans the padded box with 255 / 254 of its extent
+constexpr float kWideInvCells = 1.0f / 254.0f;   // one cell of the byte grid, as a fraction of the node's box
 
 struct Texture {
     uint32_t offset;   // element offset into texels_f32 (floats) or texels_u8 (bytes)
@@ -134,7 +134,8 @@ struct SceneView {
     // The 4-wide tree of the ordered, distance-culled walk (n_wide == 0: the scene has none).
     const WideNode* wide;
     uint32_t n_wide;
-    float wide_pad;          // every decoded slot box contains its real box grown by this
+    float wide_pad;          // every decoded slot box, grown by this, contains its real box (wide_bvh.h)
+    float wide_grow0;        // wide_pad * (1 + 2 * kWideSlack): what a slot box is grown by before the distance term
     float wide_org_bound;    // rays with an origin component beyond this take the unculled walk
 };
 

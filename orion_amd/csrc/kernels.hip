@@ -599,7 +599,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     if (!items.empty()) { if ((rc = upload(s, items, &v.items))) return bail(rc); v.n_items = 64; }
     if (!wide.nodes.empty()) {
         if ((rc = upload(s, wide.nodes, &v.wide))) return bail(rc);
-        v.n_wide = (uint32_t)wide.nodes.size(); v.wide_pad = wide.pad; v.wide_org_bound = wide.org_bound;
+        v.n_wide = (uint32_t)wide.nodes.size(); v.wide_pad = wide.pad; v.wide_grow0 = wide.pad * (1.0f + 2.0f * kWideSlack); v.wide_org_bound = wide.org_bound;
     }
     s->wide_why_not = wide.why_not;
     {   // |det| = |e1 . (d x e2)| <= 6 D E^2 for direction components up to D and edge components up to E;
@@ -993,6 +993,16 @@ int orion_hip_camera_vectors(const float eye[3], const float look_at[3], const f
     out->up[0] = vUp.x; out->up[1] = vUp.y; out->up[2] = vUp.z;
     return 0;
 }
+
+#if ORION_WIDE_STATS
+// Builds with -DORION_WIDE_STATS=1 only: the lane-occupancy counters of the ray-drawing loop (pathtrace.h).
+int orion_hip_debug_wide_stats(unsigned long long* out16, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wide_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stats), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 int orion_hip_profile_enable(OrionScene* s, int enable) {
     if (!s) return fail(1, "profile_enable: scene is null");

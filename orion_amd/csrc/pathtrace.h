@@ -165,6 +165,15 @@ constexpr uint32_t kQueryGrab = ORION_QUERY_GRAB;       // most rays a wave take
 constexpr uint32_t kWorkParts = 16, kWorkCounters = 64, kWorkWords = kWorkCounters + 16 * kWorkParts;   // layout of the work words
 constexpr uint32_t kCoherentChunks = 16;                // 64-ray chunks per block of k_query_coherent
 
+#ifndef ORION_DRAW_WAVES
+#define ORION_DRAW_WAVES 0
+#endif
+#if ORION_DRAW_WAVES
+#define ORION_DRAW_ATTR __attribute__((amdgpu_waves_per_eu(ORION_DRAW_WAVES, ORION_DRAW_WAVES)))
+#else
+#define ORION_DRAW_ATTR
+#endif
+
 template <bool ANY>
 __device__ __forceinline__ void query_store(const SceneView& S, uint32_t i, const HitRec& h, OrionHit* __restrict__ out, uint8_t* __restrict__ occ) {
     if (ANY) { occ[i] = h.gtri != kInvalid ? 1 : 0; return; }
@@ -300,6 +309,19 @@ __device__ __forceinline__ void wide_deliver(WideState& w, HitRec& h, bool slow,
     }
 }
 
+// Lane-occupancy counters of the loop below, for builds with -DORION_WIDE_STATS=1 only (tools/ab/wide_stats.py):
+// [0] outer turns  [1] node steps  [2] lanes in them  [3] leaf steps  [4] lanes in them  [5] triangle turns (longest leaf of
+// each step)  [6] lane-triangles  [7] refills  [8] rays handed out  [9] rounds of sharing  [10] unculled walks  [11] waves
+#ifndef ORION_WIDE_STATS
+#define ORION_WIDE_STATS 0
+#endif
+#if ORION_WIDE_STATS
+__device__ unsigned long long g_wide_stats[16];
+#define WIDE_STAT(k, v) (stat[k] += (v))
+#else
+#define WIDE_STAT(k, v) ((void)0)
+#endif
+
 // The loop of a wave that draws rays: load(i, o, d) fetches ray i, store(i, h) takes its result.
 template <bool ANY, bool LISTED, typename Load, typename Store>
 __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, uint32_t grab, uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks,
@@ -320,7 +342,11 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
     bool quick_det = false, slow = false;
     // Sharing (see wide_share): the lane whose ray this lane walks a part of, and how many lanes walk parts of this lane's.
     uint32_t owner = kNoOwner, lent = 0u;
+#if ORION_WIDE_STATS
+    uint32_t stat[12] = {};
+#endif
     for (;;) {
+        WIDE_STAT(0, 1u);
 #if ORION_WIDE_SHARE
         if (pool_empty) wide_deliver(w, h, slow, owner, lent);
 #endif
@@ -346,6 +372,7 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
             if (!pool_empty) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mi, 0u));
                 const uint32_t i = g_next + rank;
+                WIDE_STAT(7, 1u); WIDE_STAT(8, (uint32_t)__popcll(__ballot(idle && i < g_end)));
                 if (idle && i < g_end) {
                     load(i, o, d);
                     bool d_small, d_normal;
@@ -364,12 +391,14 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
 #if ORION_WIDE_SHARE
         if (pool_empty) sharing = wide_share(w, o, d, inv, h, quick_det, slow, idle, owner, lent);
 #endif
+        if (sharing) WIDE_STAT(9, 1u);
         if (__ballot(w.cur != kWideEmpty || slow) == 0ull) {
             if (pool_empty && __ballot(ray != kInvalid || owner != kNoOwner) == 0ull) break;
             continue;
         }
         // rays the wide walk does not take, and lanes whose stack overflowed: the unculled walk
         if (__any(slow)) {
+            WIDE_STAT(10, 1u);
             if (slow) {
                 h = miss_rec(); traverse_lane<ANY>(S, o, d, h); slow = false; w.cur = kWideEmpty;
                 w.best_slot = h.gtri != kInvalid ? S.slot_of[h.gtri] : 0u;   // (the result rule of shared rays compares slots)
@@ -382,20 +411,33 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
             if (!__any(at_node)) break;
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kLeafQuorumWide) break;
             if (!pool_empty && (uint32_t)__popcll(__ballot(w.cur == kWideEmpty && !slow)) >= kRefillMin) break;
+            WIDE_STAT(1, 1u); WIDE_STAT(2, (uint32_t)__popcll(__ballot(at_node)));
             if (at_node && !wide_node_step(S, o, inv, h.t, w, tid)) slow = true;
             if (sharing && __any(w.sp != 0u && w.cur != kWideEmpty)) break;   // somebody has a part to hand out
         }
         const bool at_leaf = wide_at_leaf(w);
         const bool all_quick = __all(!at_leaf || quick_det);
+#if ORION_WIDE_STATS
+        if (__any(at_leaf)) {
+            const uint32_t cnt = at_leaf ? (w.cur >> 25) & 63u : 0u;
+            uint32_t mx = cnt, sum = cnt;
+            for (int sft = 1; sft < 64; sft <<= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft)); sum += (uint32_t)__shfl_xor((int)sum, sft); }
+            stat[3] += 1u; stat[4] += (uint32_t)__popcll(__ballot(at_leaf)); stat[5] += mx; stat[6] += sum;
+        }
+#endif
         if (at_leaf) {
             if (all_quick) wide_leaf_step<ANY, true>(S, o, d, h, w, tid);
             else wide_leaf_step<ANY, false>(S, o, d, h, w, tid);
         }
     }
+#if ORION_WIDE_STATS
+    stat[11] = 1u;
+    if (lane == 0u) for (int k = 0; k < 12; k++) atomicAdd(&g_wide_stats[k], (unsigned long long)stat[k]);
+#endif
 }
 
 template <bool ANY, bool LISTED>
-__global__ __launch_bounds__(kBlock) void k_query_wide(SceneView S, const float* __restrict__ org, const float* __restrict__ dir, uint32_t n,
+__global__ __launch_bounds__(kBlock) ORION_DRAW_ATTR void k_query_wide(SceneView S, const float* __restrict__ org, const float* __restrict__ dir, uint32_t n,
                                                        OrionHit* __restrict__ out, uint8_t* __restrict__ occ,
                                                        uint32_t grab, uint32_t* __restrict__ work, const uint32_t* __restrict__ chunks) {
     wide_draw_rays<ANY, LISTED>(S, n, grab, work, chunks,
@@ -518,7 +560,7 @@ __global__ void k_publish(const unsigned long long* cnt, unsigned long long* pub
 // waves of a launch that just fills the chip draw rays from the queue as their lanes finish
 // (wide_draw_rays).  Hits go to pre_hits[i], ray by ray; k_extend<MODE_PRE> then compacts them as it
 // compacts its own.  work: the grab counters, zero at launch (k_extend<MODE_PRE> resets them).
-__global__ __launch_bounds__(kBlock) void k_extend_wide(SceneView S, Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
+__global__ __launch_bounds__(kBlock) ORION_DRAW_ATTR void k_extend_wide(SceneView S, Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
                                                         float4* __restrict__ pre_hits, uint32_t grab, uint32_t* __restrict__ work) {
     uint32_t n = n_bound;
     if (prev) { const unsigned long long m = prev[1]; if (m < n) n = (uint32_t)m; }

@@ -31,16 +31,14 @@ using orion_dev::kWideLeaf;
 using orion_dev::kWideMaxLeaf;
 using orion_dev::kWideSlack;
 
-constexpr float kInvCells = orion_dev::kWideInvCells;
-
-// The grid of a wide node along one axis; the walk computes the same two numbers with the same operations.
-inline float grid_origin(float lo, float pad) { return lo - pad; }
-inline float grid_cell(float lo, float hi, float pad) { return ((hi - lo) + 2.0f * pad) * kInvCells; }
-inline float grid_decode(uint32_t q, float cell, float origin) { return std::fmaf((float)q, cell, origin); }   // (the walk folds this into its slab arithmetic)
+// The grid of a wide node along one axis: 254 cells from the lower to the upper bound of the node's own box
+// (byte 255 lies one cell beyond the upper bound).  The walk never decodes a byte into a coordinate: it places
+// the grid's planes between the two slab distances of the node's own box (wide_walk.h).
+inline double grid_decode(uint32_t q, float lo, float hi) { return (double)lo + (double)q * (((double)hi - (double)lo) * (1.0 / 254.0)); }
 
 struct WideTree {
     std::vector<WideNode> nodes;   // nodes[0] is the root; empty: the scene is not eligible
-    float pad = 0.0f;              // every decoded slot box contains the real box grown by this
+    float pad = 0.0f;              // every decoded slot box, grown by this, contains the real box grown by three quarters of it
     float org_bound = 0.0f;        // rays with an origin component beyond this take the unculled walk
     uint32_t stack_need = 0;       // deepest the ordered walk's stack can get
     std::string why_not;           // set when nodes is empty
@@ -232,16 +230,19 @@ inline WideTree build_wide_tree(const OrionMeshDesc* meshes, uint32_t n_meshes, 
                 need.push_back(0); parent.push_back(job.index);
             }
             for (int a = 0; a < 3; a++) {
-                const float origin = grid_origin(own.lo[a], out.pad), cell = grid_cell(own.lo[a], own.hi[a], out.pad);
-                const float want_lo = c.box.lo[a] - out.pad, want_hi = c.box.hi[a] + out.pad;
-                int ql = cell > 0.0f ? (int)std::floor((want_lo - origin) / cell) : 0;
-                int qh = cell > 0.0f ? (int)std::ceil((want_hi - origin) / cell) : 255;
-                ql = std::min(255, std::max(0, ql)); qh = std::min(255, std::max(0, qh));
-                while (ql > 0 && grid_decode((uint32_t)ql, cell, origin) > want_lo) ql--;
-                while (qh < 255 && grid_decode((uint32_t)qh, cell, origin) < want_hi) qh++;
-                // a leaf's triangles may poke out of the parent's box by the rounding of an edge vector: the
-                // ends of the grid lie a quarter pad or more beyond anything accepted above
-                if (grid_decode((uint32_t)ql, cell, origin) > c.box.lo[a] - 0.5f * out.pad || grid_decode((uint32_t)qh, cell, origin) < c.box.hi[a] + 0.5f * out.pad)
+                const float lo = own.lo[a], hi = own.hi[a];
+                int ql = 0, qh = 0;
+                if (hi > lo) {
+                    const double cells = 254.0 / ((double)hi - (double)lo);
+                    ql = (int)std::floor(((double)c.box.lo[a] - lo) * cells);
+                    qh = (int)std::ceil(((double)c.box.hi[a] - lo) * cells);
+                    ql = std::min(255, std::max(0, ql)); qh = std::min(255, std::max(0, qh));
+                    while (ql > 0 && grid_decode((uint32_t)ql, lo, hi) > c.box.lo[a]) ql--;
+                    while (qh < 255 && grid_decode((uint32_t)qh, lo, hi) < c.box.hi[a]) qh++;
+                }
+                // a leaf's triangles may poke out of the parent's box by the rounding of an edge vector (a quarter
+                // pad at most was accepted above): the walk grows every decoded box by the pad
+                if (grid_decode((uint32_t)ql, lo, hi) > (double)c.box.lo[a] + 0.25 * out.pad || grid_decode((uint32_t)qh, lo, hi) < (double)c.box.hi[a] - 0.25 * out.pad)
                     return refuse("a slot box does not fit its node's grid");
                 wn.qlo[a] |= (uint32_t)ql << (8 * k);
                 wn.qhi[a] |= (uint32_t)qh << (8 * k);

@@ -12,8 +12,8 @@
 //     with the smallest t and, among equal t, the LAST triangle in its visit order.  Triangle slots are
 //     stored in that order (meshes in load order, each tree depth first), so in any visiting order
 //     "t < best, or t == best and slot > best slot" selects the same triangle with the same t, u, v.
-//   * Skipping.  A slot's decoded box contains the slot's real box grown by the scene's pad, and the walk
-//     grows it further by kWideSlack times the origin's distance to the farthest corner of the node's grid.  An inner slot
+//   * Skipping.  A slot's decoded box is grown by the scene's pad (it then contains the slot's real box) and further by
+//     kWideSlack times (the origin's distance to the farthest corner of the node's box + two pads).  An inner slot
 //     missed by the ray would fail the reference's own test on the (smaller) real box.  Two more skips
 //     rest on one assumption, that the reference's computed hit point o + t*d of a triangle it accepts
 //     lies inside the triangle's box grown by that much: a leaf whose grown box the ray misses, and any
@@ -41,15 +41,17 @@ constexpr int kWideStack = ORION_WIDE_STACK;     // stack entries per lane (LDS:
 
 // One lane's stack entry: what to visit (4 bytes) and where its grown box begins along the ray, as the
 // upper half of the float rounded down (2 bytes: a bound from below is all the entry is used for).
-// [depth][thread]: a lane's entries sit in the same banks at every depth.
-__shared__ uint32_t g_wide_ref[kWideStack][kWideBlock];
-__shared__ uint16_t g_wide_t[kWideStack][kWideBlock];
+// [depth][thread]: a lane's entries sit in the same banks at every depth.  One row more than the stack is
+// deep: a node step writes its candidates without asking which of them count (wide_node_step), and the one
+// that does not count lands on the first free row.
+__shared__ uint32_t g_wide_ref[kWideStack + 1][kWideBlock];
+__shared__ uint16_t g_wide_t[kWideStack + 1][kWideBlock];
 
 __device__ __forceinline__ void wide_push(uint32_t sp, uint32_t tid, uint32_t ref, float tmin) {
     // Upper 16 bits: truncation rounds a positive float down; a negative entry distance (origin inside
     // the box) becomes 0, which is below every best hit as well.
     g_wide_ref[sp][tid] = ref;
-    g_wide_t[sp][tid] = (uint16_t)(__float_as_uint(fmaxf(tmin, 0.0f)) >> 16);
+    g_wide_t[sp][tid] = (uint16_t)(__float_as_uint(vmax(tmin, 0.0f)) >> 16);
 }
 
 // (compiles to one v_cvt_f32_ubyteK)
@@ -66,23 +68,27 @@ __device__ __forceinline__ void wide_pop(WideState& w, float best, uint32_t tid)
     w.cur = kWideEmpty;
     while (w.sp) {
         w.sp--;
+        const uint32_t ref = g_wide_ref[w.sp][tid];   // (both halves of the entry in one round trip)
         const float t = __uint_as_float((uint32_t)g_wide_t[w.sp][tid] << 16);
-        if (!(t > best)) { w.cur = g_wide_ref[w.sp][tid]; break; }
+        if (!(t > best)) { w.cur = ref; break; }
     }
 }
 
-// Slot K's entry distance, or +inf if the slot is empty, missed, behind the origin or beyond `best`.
-// The slab distances come straight from the bytes: (byte * cell + origin -+ r - o) * inv, multiplied out
-// (c = cell * inv, l / u = (origin - o -+ r) * inv); its rounding is ten-thousandths of the slack r.
+__device__ __forceinline__ float vmax3_abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Slot K's entry distance, or +inf if the slot is empty, missed, behind the origin or beyond
+// `best`.  The slab distances of the grown box come straight from the bytes: byte * c + l for a lower bound,
+// byte * c + u for an upper bound (wide_node_step computes c, l, u per axis).
 template <int K>
 __device__ __forceinline__ float wide_slot(const float4& C, const float4& D, V3 c, V3 l, V3 u, float best, uint32_t ref) {
     const float t1x = fmaf(byte_of<K>(__float_as_uint(C.x)), c.x, l.x), t2x = fmaf(byte_of<K>(__float_as_uint(C.w)), c.x, u.x);
     const float t1y = fmaf(byte_of<K>(__float_as_uint(C.y)), c.y, l.y), t2y = fmaf(byte_of<K>(__float_as_uint(D.x)), c.y, u.y);
     const float t1z = fmaf(byte_of<K>(__float_as_uint(C.z)), c.z, l.z), t2z = fmaf(byte_of<K>(__float_as_uint(D.y)), c.z, u.z);
+    // "tmax >= tmin, tmax >= 0, tmin <= best" with best >= 0 is "max(tmin, 0) <= min(tmax, best)"
     const float tmin = vmax3(vmin(t1x, t2x), vmin(t1y, t2y), vmin(t1z, t2z));
-    const float tmax = vmin3(vmax(t1x, t2x), vmax(t1y, t2y), vmax(t1z, t2z));
-    const bool hit = ref != kWideEmpty && tmax >= tmin && tmax >= 0.0f && tmin <= best;
-    return hit ? tmin : __builtin_inff();
+    const float tmax = vmin(vmin3(vmax(t1x, t2x), vmax(t1y, t2y), vmax(t1z, t2z)), best);
+    const bool hit = (ref != kWideEmpty) & (vmax(tmin, 0.0f) <= tmax);   // (&: no branch around the comparison)
+    return hit ? tmin : __builtin_inff();   // (a negative tmin orders the slots that hold the origin)
 }
 
 // One wide node: the reference's test on its own box, then the four slots; the nearest one is next and the
@@ -95,32 +101,42 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
     const float inf = __builtin_inff();
     float t0 = inf, t1 = inf, t2 = inf, t3 = inf;
     const uint32_t r0 = __float_as_uint(A.w), r1 = __float_as_uint(B.w), r2 = __float_as_uint(D.z), r3 = __float_as_uint(D.w);
-    if (slab_hit_fast(A.x, A.y, A.z, B.x, B.y, B.z, o, inv)) {
-        const float pad = S.wide_pad, pad2 = 2.0f * pad;
-        const V3 org = mk(A.x - pad, A.y - pad, A.z - pad);
-        const V3 cell = mk(((B.x - A.x) + pad2) * kWideInvCells, ((B.y - A.y) + pad2) * kWideInvCells, ((B.z - A.z) + pad2) * kWideInvCells);
-        const V3 n0 = org - o;                                                                          // near end of the grid, from the origin
-        const V3 n1 = mk(fmaf(255.0f, cell.x, org.x) - o.x, fmaf(255.0f, cell.y, org.y) - o.y, fmaf(255.0f, cell.z, org.z) - o.z);   // far end
-        const float reach = fmaxf(vmax3(fabsf(n0.x), fabsf(n1.x), fabsf(n0.y)), vmax3(fabsf(n1.y), fabsf(n0.z), fabsf(n1.z)));
-        const float r = kWideSlack * reach;
-        const V3 c = cell * inv;
-        const V3 l = mk((n0.x - r) * inv.x, (n0.y - r) * inv.y, (n0.z - r) * inv.z);
-        const V3 u = mk((n0.x + r) * inv.x, (n0.y + r) * inv.y, (n0.z + r) * inv.z);
+    // AABB::intersect on the node's own box (orion/AABB.hpp:79-99; the form of slab_hit_fast), keeping its terms
+    const V3 n0 = mk(A.x - o.x, A.y - o.y, A.z - o.z), n1 = mk(B.x - o.x, B.y - o.y, B.z - o.z);
+    const V3 s0 = n0 * inv, s1 = n1 * inv;
+    const float own_min = vmax3(vmin(s0.x, s1.x), vmin(s0.y, s1.y), vmin(s0.z, s1.z));
+    const float own_max = vmin3(vmax(s0.x, s1.x), vmax(s0.y, s1.y), vmax(s0.z, s1.z));
+    if (own_max > own_min && own_max > 0.0f) {
+        // The grid's plane at byte q lies at lo + q * (hi - lo) / 254; its slab distance is s0 + q * (s1 - s0) / 254, and
+        // that of a plane moved by g against / along the axis s0 -+ g * inv (the rounding of these forms is
+        // ten-thousandths of the slack).  g = pad + slack * (reach + 2 pad), reach = the origin's distance to the
+        // farthest corner of the node's box.
+        const float reach = vmax(vmax3_abs(n0.x, n1.x, n0.y), vmax3_abs(n1.y, n0.z, n1.z));
+        const float g = fmaf(kWideSlack, reach, S.wide_grow0);
+        const V3 c = mk((s1.x - s0.x) * kWideInvCells, (s1.y - s0.y) * kWideInvCells, (s1.z - s0.z) * kWideInvCells);
+        const V3 l = mk(fmaf(-g, inv.x, s0.x), fmaf(-g, inv.y, s0.y), fmaf(-g, inv.z, s0.z));
+        const V3 u = mk(fmaf(g, inv.x, s0.x), fmaf(g, inv.y, s0.y), fmaf(g, inv.z, s0.z));
         t0 = wide_slot<0>(C, D, c, l, u, best, r0);
         t1 = wide_slot<1>(C, D, c, l, u, best, r1);
         t2 = wide_slot<2>(C, D, c, l, u, best, r2);
         t3 = wide_slot<3>(C, D, c, l, u, best, r3);
     }
-    const float tn = fminf(fminf(t0, t1), fminf(t2, t3));
+    const float tn = vmin(vmin3(t0, t1, t2), t3);
     if (!(tn < inf)) { wide_pop(w, best, tid); return true; }
-    const uint32_t kn = t0 == tn ? 0u : (t1 == tn ? 1u : (t2 == tn ? 2u : 3u));
-    const bool p0 = t0 < inf && kn != 0u, p1 = t1 < inf && kn != 1u, p2 = t2 < inf && kn != 2u, p3 = t3 < inf && kn != 3u;
-    if (w.sp + (p0 ? 1u : 0u) + (p1 ? 1u : 0u) + (p2 ? 1u : 0u) + (p3 ? 1u : 0u) > (uint32_t)kWideStack) { w.cur = kWideEmpty; return false; }
-    if (p3) { wide_push(w.sp, tid, r3, t3); w.sp++; }
-    if (p2) { wide_push(w.sp, tid, r2, t2); w.sp++; }
-    if (p1) { wide_push(w.sp, tid, r1, t1); w.sp++; }
-    if (p0) { wide_push(w.sp, tid, r0, t0); w.sp++; }
-    w.cur = kn == 0u ? r0 : (kn == 1u ? r1 : (kn == 2u ? r2 : r3));
+    // The first slot at distance tn is next; the other slots that were hit go onto the stack, the farthest slot
+    // number first.  No branches: every candidate is written to the row above the stack and the stack only
+    // grows past it if the candidate counts (the spare row takes the last one that does not).
+    const bool e0 = t0 == tn, e1 = t1 == tn, e2 = t2 == tn;
+    const bool p0 = (t0 < inf) & !e0, p1 = (t1 < inf) & (e0 | !e1), p2 = (t2 < inf) & (e0 | e1 | !e2), p3 = (t3 < inf) & (e0 | e1 | e2);
+    const uint32_t more = (p0 ? 1u : 0u) + (p1 ? 1u : 0u) + (p2 ? 1u : 0u) + (p3 ? 1u : 0u);
+    if (w.sp + more > (uint32_t)kWideStack) { w.cur = kWideEmpty; return false; }
+    uint32_t sp = w.sp;
+    wide_push(sp, tid, r3, t3); sp += p3 ? 1u : 0u;
+    wide_push(sp, tid, r2, t2); sp += p2 ? 1u : 0u;
+    wide_push(sp, tid, r1, t1); sp += p1 ? 1u : 0u;
+    wide_push(sp, tid, r0, t0); sp += p0 ? 1u : 0u;
+    w.sp = sp;
+    w.cur = e0 ? r0 : (e1 ? r1 : (e2 ? r2 : r3));
     return true;
 }
 
