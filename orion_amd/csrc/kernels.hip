@@ -1002,6 +1002,10 @@ int orion_hip_debug_wide_stats(unsigned long long* out16, int reset) {
     if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stats), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
 }
+int orion_hip_debug_wide_times(unsigned long long* out8192x4) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out8192x4, HIP_SYMBOL(g_wide_times), 8192 * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 #endif
 
 int orion_hip_profile_enable(OrionScene* s, int enable) {

@@ -258,10 +258,16 @@ __device__ __forceinline__ bool wide_share(WideState& w, V3& o, V3& d, V3& inv, 
     const bool takes = idle && rank_t < n, gives = give && rank_g < n;
     if (takes) g_wide_taker[wave0 + rank_t] = (uint8_t)lane;
     wave_lds_fence();
+    // What a lane hands out is the BOTTOM entry of its stack: the farthest and, as a rule, the largest of the subtrees
+    // it has yet to visit (the top entry is what it would visit next itself, usually a few nodes; handing those
+    // out leaves the long rays as long as they were).  The entries above move down one row.
+    uint32_t ref = 0u, tb = 0u;
+    if (gives) { ref = g_wide_ref[0][tid]; tb = g_wide_t[0][tid]; }
+    for (uint32_t k = 1; __any(gives && k < w.sp); k++)
+        if (gives && k < w.sp) { g_wide_ref[k - 1][tid] = g_wide_ref[k][tid]; g_wide_t[k - 1][tid] = g_wide_t[k][tid]; }
     if (gives) {
         const uint32_t col = wave0 + g_wide_taker[wave0 + rank_g];   // the taker's stack column: empty, it carries the part
         w.sp--;
-        const uint32_t ref = g_wide_ref[w.sp][tid], tb = g_wide_t[w.sp][tid];
         g_wide_ref[0][col] = __float_as_uint(o.x); g_wide_ref[1][col] = __float_as_uint(o.y); g_wide_ref[2][col] = __float_as_uint(o.z);
         g_wide_ref[3][col] = __float_as_uint(d.x); g_wide_ref[4][col] = __float_as_uint(d.y); g_wide_ref[5][col] = __float_as_uint(d.z);
         g_wide_ref[6][col] = __float_as_uint(h.t); g_wide_ref[7][col] = __float_as_uint(h.u); g_wide_ref[8][col] = __float_as_uint(h.v);
@@ -317,7 +323,12 @@ __device__ __forceinline__ void wide_deliver(WideState& w, HitRec& h, bool slow,
 #endif
 #if ORION_WIDE_STATS
 __device__ unsigned long long g_wide_stats[16];
+__device__ unsigned long long g_wide_times[8192][4];   // per wave: start, pool empty, end (s_memrealtime, 100 MHz), rays walked
+#if ORION_WIDE_STATS == 1
 #define WIDE_STAT(k, v) (stat[k] += (v))
+#else
+#define WIDE_STAT(k, v) ((void)0)     // ORION_WIDE_STATS=2: the per-wave times only; 3: start and end only
+#endif
 #else
 #define WIDE_STAT(k, v) ((void)0)
 #endif
@@ -344,6 +355,8 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
     uint32_t owner = kNoOwner, lent = 0u;
 #if ORION_WIDE_STATS
     uint32_t stat[12] = {};
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_empty = 0ull;
 #endif
     for (;;) {
         WIDE_STAT(0, 1u);
@@ -364,7 +377,12 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
                     if (k < part_grabs && part * part_grabs + k < n_grabs) { g = part * part_grabs + k; break; }
                     part = (part + 1u) % kWorkParts; parts_done++;   // this range is used up: on to the next
                 }
-                if (g >= n_grabs) pool_empty = true;
+                if (g >= n_grabs) {
+                    pool_empty = true;
+#if ORION_WIDE_STATS && ORION_WIDE_STATS != 3
+                    t_empty = __builtin_amdgcn_s_memrealtime();
+#endif
+                }
                 else if (LISTED) { l_next = g * (grab / 64u); l_end = min(n_listed, l_next + grab / 64u); }
                 else { g_next = g * grab; g_end = min(n, g_next + grab); }
             }
@@ -417,7 +435,7 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
         }
         const bool at_leaf = wide_at_leaf(w);
         const bool all_quick = __all(!at_leaf || quick_det);
-#if ORION_WIDE_STATS
+#if ORION_WIDE_STATS == 1
         if (__any(at_leaf)) {
             const uint32_t cnt = at_leaf ? (w.cur >> 25) & 63u : 0u;
             uint32_t mx = cnt, sum = cnt;
@@ -432,7 +450,16 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
     }
 #if ORION_WIDE_STATS
     stat[11] = 1u;
-    if (lane == 0u) for (int k = 0; k < 12; k++) atomicAdd(&g_wide_stats[k], (unsigned long long)stat[k]);
+    if (lane == 0u) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+#if ORION_WIDE_STATS == 1
+        for (int k = 0; k < 12; k++) atomicAdd(&g_wide_stats[k], (unsigned long long)stat[k]);   // (thousands of waves on twelve addresses: this lengthens the launch)
+#else
+        atomicAdd(&g_wide_stats[11], 1ull);
+#endif
+        const uint32_t wv = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        if (wv < 8192u) { g_wide_times[wv][0] = t_start; g_wide_times[wv][1] = t_empty; g_wide_times[wv][2] = t_end; g_wide_times[wv][3] = stat[8]; }
+    }
 #endif
 }
 

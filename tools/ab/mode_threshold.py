@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does the wave-synchronous walk stop paying?  Closest-hit throughput of both walks on
+"""Where does the wave-synchronous walk stop paying?  Closest-hit throughput of the three walks on
 tessellated spheres of growing size (one connected mesh over a ground quad), for rays in pixel
 order (coherent), cosine bounce rays and rays towards surface points.
 Usage: python tools/ab/mode_threshold.py [triangle counts ...]"""
@@ -65,8 +65,12 @@ def main():
             to, td = torch.from_numpy(np.ascontiguousarray(o)).cuda(), torch.from_numpy(np.ascontiguousarray(d)).cuda()
             out = torch.empty((len(o), 5), dtype=torch.int32, device="cuda")
             rates = []
-            for mode in (1, 2):
-                sc.set_option("traversal", mode)
+            for mode in (1, 2, 4):
+                try:
+                    sc.set_option("traversal", mode)
+                except api.OrionError:
+                    rates.append(0.0)
+                    continue
                 sc.closest_hit(to, td, out)
                 sc.profile(True)
                 for _ in range(3):
@@ -74,7 +78,7 @@ def main():
                 st = sc.profile_read()["closest_hit"]
                 sc.profile(False)
                 rates.append(st["items"] / st["ms"] / 1e6)
-            line += f" {bname}: lane {rates[0]:6.2f} wave {rates[1]:6.2f} G/s |"
+            line += f" {bname}: lane {rates[0]:6.2f} wave {rates[1]:6.2f} wide {rates[2]:6.2f} G/s |"
         print(line, flush=True)
         sc.close()
 

@@ -17,6 +17,7 @@ def main():
     from orion_amd import api
     L = api.lib()
     L.orion_hip_debug_wide_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.orion_hip_debug_wide_times.argtypes = [ctypes.c_void_p]
     n = 1 << int(os.environ.get("RAYS_LOG2", "22"))
     for name in sys.argv[1:] or ["nanosuit", "soup"]:
         model = conftest.load_model(name)
@@ -51,6 +52,13 @@ def main():
             print(f"   node steps {nsteps} with {nlanes / max(1, nsteps):.1f} lanes; leaf steps {lsteps} with {llanes / max(1, lsteps):.1f} lanes, "
                   f"{trips / max(1, lsteps):.2f} triangle turns each ({ltris / max(1, trips):.1f} lanes per turn); outer turns {outer}; "
                   f"refills {refills} handing out {handed / max(1, refills):.1f} rays; share rounds {shares}; unculled {slow}")
+            tm = np.zeros((8192, 4), np.uint64)
+            L.orion_hip_debug_wide_times(tm.ctypes.data_as(ctypes.c_void_p))
+            tm = tm[:waves].astype(np.int64)
+            t0 = tm[:, 0].min()
+            us = lambda a: (a - t0) / 100.0
+            q = lambda a: " ".join(f"{x:.0f}" for x in np.percentile(us(a), [0, 10, 50, 90, 99, 100]))
+            print(f"   per wave, microseconds after the first wave's start (min p10 p50 p90 p99 max): start {q(tm[:, 0])} | pool empty {q(tm[:, 1])} | end {q(tm[:, 2])}; rays per wave min/mean/max {tm[:, 3].min()}/{tm[:, 3].mean():.0f}/{tm[:, 3].max()}")
             print(f"   wave-level per ray: node steps {nsteps / n:.3f}  triangle turns {trips / n:.3f}  outer turns {outer / n:.3f}  refills {refills / n:.3f}")
         sc.close()
 
