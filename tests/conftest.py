@@ -38,6 +38,11 @@ def load_model(name: str):
             import raygen
             v, i = raygen.triangle_soup()
             _models[name] = host.model_from_arrays(v, i)
+        elif name.startswith("soup") and name[4:].isdigit():      # "soup20": 2^20 triangles at the same density of coverage
+            import raygen
+            n = 1 << int(name[4:])
+            v, i = raygen.triangle_soup(n, edge=0.02 * (19058 / n) ** (1 / 3), seed=2)
+            _models[name] = host.model_from_arrays(v, i)
         else:
             _models[name] = host.load_model(scene_path(name))
     return _models[name]
