@@ -133,6 +133,7 @@ struct SceneView {
     float dir_bound;
     // The 4-wide tree of the ordered, distance-culled walk (n_wide == 0: the scene has none).
     const WideNode* wide;
+    const uint32_t* wide_bin;   // per wide node: index in `nodes` of the binary inner node it stands for (kInvalid: a virtual node)
     uint32_t n_wide;
     float wide_pad;          // every decoded slot box, grown by this, contains its real box (wide_bvh.h)
     float wide_grow0;        // wide_pad * (1 + 2 * kWideSlack): what a slot box is grown by before the distance term

@@ -171,10 +171,13 @@ __device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+
 // the one-slot rate on bounce rays; quorum 8, 16, 32 are within 3 % of each other.
 constexpr int kLeafSlots = 6, kLeafQuorum = 16;
 
+// Walks nodes [begin, end) of the threaded array: the whole scene, or the subtree of the inner node at
+// `begin` with end = its skip link (in depth-first preorder a subtree is a contiguous range and no link
+// inside it points past its end).
 template <bool ANY, bool QUICK>
-__device__ __forceinline__ void traverse_lane_walk(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, HitRec& h) {
-    uint32_t node = 0;
-    const uint32_t n_nodes = S.n_nodes;
+__device__ __forceinline__ void traverse_lane_walk(const SceneView& S, V3 o, V3 d, V3 inv, bool fast, HitRec& h, uint32_t begin, uint32_t end) {
+    uint32_t node = begin;
+    const uint32_t n_nodes = end;
     constexpr int K = kLeafSlots;
     uint32_t first[K], cnt[K];   // the leaves this lane has yet to test, in visit order (registers: every index below is a constant)
 #pragma unroll
@@ -226,8 +229,8 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
     const bool quick_det = __all(d_small), quick_inv = __all(d_normal);   // wave-uniform choices of the arithmetic
     const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
     const bool fast = quick_inv ? __all(finite3(o)) : __all(slab_safe(o, inv));
-    if (quick_det) traverse_lane_walk<ANY, true>(S, o, d, inv, fast, h);
-    else traverse_lane_walk<ANY, false>(S, o, d, inv, fast, h);
+    if (quick_det) traverse_lane_walk<ANY, true>(S, o, d, inv, fast, h, 0u, S.n_nodes);
+    else traverse_lane_walk<ANY, false>(S, o, d, inv, fast, h, 0u, S.n_nodes);
 }
 
 // ---------------------------------------------------------------------------

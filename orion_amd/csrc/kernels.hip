@@ -220,6 +220,7 @@ struct Flattener {
     std::vector<Node>& nodes;
     std::vector<uint8_t> seen;
     std::string err;
+    std::vector<uint32_t> where = {};   // caller's node index -> index in `nodes`
 
     // Emits the subtree of `ni`; returns false on malformed input.
     bool emit(uint32_t ni) {
@@ -237,6 +238,8 @@ struct Flattener {
             if (it.node >= m.n_nodes) { err = "BVH child index out of range"; return false; }
             if (seen[it.node]) { err = "BVH node reachable twice (not a tree)"; return false; }
             seen[it.node] = 1;
+            if (where.empty()) where.assign(m.n_nodes, kInvalid);
+            where[it.node] = (uint32_t)nodes.size();
             const OrionBvhNode& src = m.nodes[it.node];
             Node n;
             std::memcpy(n.lo, src.lo, 12); std::memcpy(n.hi, src.hi, 12);
@@ -443,6 +446,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
 
     uint32_t tri_base = 0;
     std::vector<uint32_t> slot_bases;
+    std::vector<std::vector<uint32_t>> node_where;   // per mesh: caller's node index -> index in `nodes`
     for (uint32_t mi = 0; mi < n_meshes; mi++) {
         const OrionMeshDesc& m = meshes[mi];
         const std::string where = "scene_create: mesh " + std::to_string(mi) + ": ";
@@ -461,9 +465,11 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
 
         const uint32_t slot_base = (uint32_t)tris.size();
         slot_bases.push_back(slot_base);
+        node_where.emplace_back();
         if (m.n_nodes) {
             Flattener fl{m, slot_base, nodes, std::vector<uint8_t>(m.n_nodes, 0), std::string()};
             if (!fl.emit(0)) return fail(1, where + fl.err);
+            node_where.back() = std::move(fl.where);
         }
         // triangle slots in tri_order (= visit order inside the mesh)
         const OrionMaterialDesc& md = materials[m.material];
@@ -598,6 +604,12 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     v.n_meshes = n_meshes; v.n_emissive = (uint32_t)emissive.size();
     if (!items.empty()) { if ((rc = upload(s, items, &v.items))) return bail(rc); v.n_items = 64; }
     if (!wide.nodes.empty()) {
+        // the binary node each wide node stands for, as an index into the threaded array (the walk hands a subtree
+        // its stack cannot hold to the unculled walk)
+        std::vector<uint32_t> wide_bin(wide.nodes.size(), kInvalid);
+        for (size_t i = 0; i < wide.nodes.size(); i++)
+            if (wide.src_mesh[i] != kInvalid) wide_bin[i] = node_where[wide.src_mesh[i]][wide.src_node[i]];
+        if ((rc = upload(s, wide_bin, &v.wide_bin))) return bail(rc);
         if ((rc = upload(s, wide.nodes, &v.wide))) return bail(rc);
         v.n_wide = (uint32_t)wide.nodes.size(); v.wide_pad = wide.pad; v.wide_grow0 = wide.pad * (1.0f + 2.0f * kWideSlack); v.wide_org_bound = wide.org_bound;
     }

@@ -163,7 +163,10 @@ constexpr uint32_t kRefillMin = ORION_REFILL_MIN;       // lanes out of work bef
 constexpr uint32_t kLeafQuorumWide = ORION_LEAF_QUORUM; // lanes waiting at a leaf before the wave turns to the triangles
 constexpr uint32_t kQueryGrab = ORION_QUERY_GRAB;       // most rays a wave takes from the global counter at a time
 constexpr uint32_t kWorkParts = 16, kWorkCounters = 64, kWorkWords = kWorkCounters + 16 * kWorkParts;   // layout of the work words
-constexpr uint32_t kCoherentChunks = 16;                // 64-ray chunks per block of k_query_coherent
+#ifndef ORION_COHERENT_CHUNKS
+#define ORION_COHERENT_CHUNKS 16
+#endif
+constexpr uint32_t kCoherentChunks = ORION_COHERENT_CHUNKS;                // 64-ray chunks per block of k_query_coherent
 
 #ifndef ORION_DRAW_WAVES
 #define ORION_DRAW_WAVES 0
@@ -430,7 +433,10 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kLeafQuorumWide) break;
             if (!pool_empty && (uint32_t)__popcll(__ballot(w.cur == kWideEmpty && !slow)) >= kRefillMin) break;
             WIDE_STAT(1, 1u); WIDE_STAT(2, (uint32_t)__popcll(__ballot(at_node)));
-            if (at_node && !wide_node_step(S, o, inv, h.t, w, tid)) slow = true;
+            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid);
+            if (__any(over)) {   // a stack that is full: that node's subtree goes to the unculled walk
+                if (over && !wide_overflow<ANY>(S, o, d, inv, false, h, w, tid)) slow = true;
+            }
             if (sharing && __any(w.sp != 0u && w.cur != kWideEmpty)) break;   // somebody has a part to hand out
         }
         const bool at_leaf = wide_at_leaf(w);

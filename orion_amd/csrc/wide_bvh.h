@@ -38,6 +38,7 @@ inline double grid_decode(uint32_t q, float lo, float hi) { return (double)lo + 
 
 struct WideTree {
     std::vector<WideNode> nodes;   // nodes[0] is the root; empty: the scene is not eligible
+    std::vector<uint32_t> src_mesh, src_node;   // per wide node: the caller's mesh and node it stands for (0xFFFFFFFF: a virtual node)
     float pad = 0.0f;              // every decoded slot box, grown by this, contains the real box grown by three quarters of it
     float org_bound = 0.0f;        // rays with an origin component beyond this take the unculled walk
     uint32_t stack_need = 0;       // deepest the ordered walk's stack can get
@@ -83,12 +84,13 @@ inline WideTree build_wide_tree(const OrionMeshDesc* meshes, uint32_t n_meshes, 
                                 const std::vector<Tri>& tris) {
     using namespace detail;
     WideTree out;
-    auto refuse = [&](const std::string& why) { out.nodes.clear(); out.why_not = why; return out; };
+    auto refuse = [&](const std::string& why) { out.nodes.clear(); out.src_mesh.clear(); out.src_node.clear(); out.why_not = why; return out; };
     if (tris.empty()) return refuse("no triangles");
     if (tris.size() >= (1u << 25)) return refuse("more than 2^25 triangles");   // a leaf reference keeps 25 bits for the slot
 
     // ---- the binary forest ---------------------------------------------------------------
     std::vector<BNode> bn;
+    std::vector<uint32_t> bn_mesh, bn_node;   // where each node of the forest comes from (virtual nodes: 0xFFFFFFFF)
     std::vector<uint32_t> roots;
     float biggest = 0.0f;
     for (uint32_t mi = 0; mi < n_meshes; mi++) {
@@ -96,6 +98,7 @@ inline WideTree build_wide_tree(const OrionMeshDesc* meshes, uint32_t n_meshes, 
         if (m.n_nodes == 0 || m.n_indices == 0) continue;
         const uint32_t base = (uint32_t)bn.size();
         bn.resize(base + m.n_nodes);
+        for (uint32_t i = 0; i < m.n_nodes; i++) { bn_mesh.push_back(mi); bn_node.push_back(i); }
         for (uint32_t i = 0; i < m.n_nodes; i++) {
             const OrionBvhNode& s = m.nodes[i];
             BNode& b = bn[base + i];
@@ -213,6 +216,8 @@ inline WideTree build_wide_tree(const OrionMeshDesc* meshes, uint32_t n_meshes, 
         }
         WideNode wn{};
         std::memcpy(wn.lo, own.lo, 12); std::memcpy(wn.hi, own.hi, 12);
+        if (out.src_mesh.size() < out.nodes.size()) { out.src_mesh.resize(out.nodes.size(), 0xFFFFFFFFu); out.src_node.resize(out.nodes.size(), 0xFFFFFFFFu); }
+        if (!job.wrapper && job.bnode < bn_mesh.size()) { out.src_mesh[job.index] = bn_mesh[job.bnode]; out.src_node[job.index] = bn_node[job.bnode]; }
         uint32_t refs[4] = {kWideEmpty, kWideEmpty, kWideEmpty, kWideEmpty};
         for (size_t k = 0; k < 4; k++) {
             if (k >= slots.size() || (bn[slots[k]].leaf && bn[slots[k]].count == 0)) {
@@ -252,6 +257,7 @@ inline WideTree build_wide_tree(const OrionMeshDesc* meshes, uint32_t n_meshes, 
         out.nodes[job.index] = wn;
         need[job.index] = (uint32_t)slots.size() - 1;
     }
+    out.src_mesh.resize(out.nodes.size(), 0xFFFFFFFFu); out.src_node.resize(out.nodes.size(), 0xFFFFFFFFu);
     // deepest stack: entries left behind on the way down (slots - 1 per node), children are created after their parents
     std::vector<uint32_t> total(out.nodes.size(), 0);
     for (size_t i = 0; i < out.nodes.size(); i++) {

@@ -92,8 +92,8 @@ __device__ __forceinline__ float wide_slot(const float4& C, const float4& D, V3 
 }
 
 // One wide node: the reference's test on its own box, then the four slots; the nearest one is next and the
-// others go onto the stack.  Returns false if the stack would overflow (the lane then has to start over
-// with the unculled walk).
+// others go onto the stack.  Returns false, with the lane still at the node, if the stack would overflow
+// (wide_overflow then deals with the node's subtree).
 __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid) {
     const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
     float4 A = np[0], B = np[1], C = np[2], D = np[3];
@@ -129,7 +129,7 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
     const bool e0 = t0 == tn, e1 = t1 == tn, e2 = t2 == tn;
     const bool p0 = (t0 < inf) & !e0, p1 = (t1 < inf) & (e0 | !e1), p2 = (t2 < inf) & (e0 | e1 | !e2), p3 = (t3 < inf) & (e0 | e1 | e2);
     const uint32_t more = (p0 ? 1u : 0u) + (p1 ? 1u : 0u) + (p2 ? 1u : 0u) + (p3 ? 1u : 0u);
-    if (w.sp + more > (uint32_t)kWideStack) { w.cur = kWideEmpty; return false; }
+    if (w.sp + more > (uint32_t)kWideStack) return false;   // (w.cur still names the node: see wide_overflow)
     uint32_t sp = w.sp;
     wide_push(sp, tid, r3, t3); sp += p3 ? 1u : 0u;
     wide_push(sp, tid, r2, t2); sp += p2 ? 1u : 0u;
@@ -160,6 +160,32 @@ __device__ __forceinline__ bool wide_leaf_step(const SceneView& S, V3 o, V3 d, H
     return false;
 }
 
+// A lane whose stack cannot take a node's slots (`over`: wide_node_step returned false; trees deeper than the
+// stack: hundreds of thousands of triangles) hands the subtree of that node to the unculled walk: the node
+// stands for a binary inner node, whose subtree is a range of the threaded array, and the reference's walk of
+// that range returns the subtree's own closest hit by the reference's rule (smallest t, among equal t the last
+// in visit order).  The lane keeps the better of that and its best so far by the same rule and goes on with its
+// stack.  Returns false for a lane that has to start its ray over with the unculled walk of the whole scene
+// (the node is a virtual one above the meshes' roots: no range).  `quick`: wave-uniform among the lanes in here
+// (the callers pass false: the path is rare and one copy of the unculled walk's code is enough).
+template <bool ANY>
+__device__ __forceinline__ bool wide_overflow(const SceneView& S, V3 o, V3 d, V3 inv, bool quick, HitRec& h, WideState& w, uint32_t tid) {
+    const uint32_t b = S.wide_bin[w.cur];
+    if (b == kInvalid) { w.cur = kWideEmpty; return false; }
+    const uint32_t end = S.nodes[b].a;   // the inner node's skip link
+    HitRec c; c.t = __builtin_inff(); c.u = 0.0f; c.v = 0.0f; c.gtri = kInvalid;
+    // (rays the wide walk takes have finite origins and reciprocals: the slab test's short form applies)
+    if (quick) traverse_lane_walk<ANY, true>(S, o, d, inv, true, c, b, end);
+    else traverse_lane_walk<ANY, false>(S, o, d, inv, true, c, b, end);
+    if (c.gtri != kInvalid) {
+        const uint32_t slot = S.slot_of[c.gtri];
+        if (c.t < h.t || (c.t == h.t && slot > w.best_slot)) { h = c; w.best_slot = slot; }
+        if (ANY) { w.cur = kWideEmpty; return true; }
+    }
+    wide_pop(w, h.t, tid);
+    return true;
+}
+
 // Which rays the wide walk takes (see the header comment).
 __device__ __forceinline__ bool wide_tame(const SceneView& S, V3 o, V3 d) {
     const int kNormal = (1 << 3) | (1 << 8);
@@ -187,7 +213,10 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
             const bool at_node = wide_at_node(w);
             if (!__any(at_node)) break;
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kStaticQuorum) break;
-            if (at_node) ok = wide_node_step(S, o, inv, h.t, w, tid) && ok;
+            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid);
+            if (__any(over)) {
+                if (over) ok = wide_overflow<ANY>(S, o, d, inv, false, h, w, tid) && ok;
+            }
         }
         if (wide_at_leaf(w)) wide_leaf_step<ANY, QUICK>(S, o, d, h, w, tid);
     }
