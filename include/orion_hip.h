@@ -190,10 +190,11 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *                 trees keep every child box inside its parent's)
  *   "tail_paths"  a render batch hands its remaining paths to the one-path-per-wave
  *                 tail kernel once at most this many are left (0 = never; small scenes only)
- *   "batch_paths" upper bound on paths in flight per render batch
+ *   "batch_paths" upper bound on paths in flight per render batch (default 256 Mi: 36 GiB of queues
+ *                 per stream; a render call takes fewer where the device's free memory asks for it)
  *   "overlap_below" a render call of several batches starts the next batch on a second
  *                 stream (with queues of its own) once the current batch has fewer rays
- *                 than this left (default 4 Mi; 0 = one batch at a time, half the memory)
+ *                 than this left (default 32 Mi; 0 = one batch at a time, half the memory)
  *   "draw_rays"   1 (default): on scenes that walk the 4-wide tree, the closest hits of bounce rays are found
  *                 by waves that draw rays from the queue as their lanes finish; 0: four rays per thread
  *   "fail_at_bounce" test hook: the n-th bounce a render call launches from now on fails (once) with

@@ -113,8 +113,8 @@ struct OrionScene {
     int traversal = 0;                // 0 auto, 1 lane, 2 wave, 3 one ray per wave at a time, 4 wide tree
     std::string wide_why_not;         // why the scene has no wide tree ("" if it has one)
     uint32_t tail_paths = 1u << 16;   // hand a batch's last paths to k_tail once this few are left
-    uint64_t batch_paths = 64u << 20;     // paths in flight per batch (128 B of queues each)
-    uint32_t overlap_below = 4u << 20;    // start the next batch on the other lane once this few rays are left (0: never)
+    uint64_t batch_paths = 256u << 20;    // paths in flight per batch (128 B of queues each; less where the device's free memory asks for it)
+    uint32_t overlap_below = 32u << 20;   // start the next batch on the other lane once this few rays are left (0: never)
     uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
     bool draw_rays = true;                // large scenes: bounce rays are handed to lanes as they finish (k_extend_wide)
     // staging + queues
@@ -793,7 +793,23 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
 
     const uint64_t P = (uint64_t)F.tile_w * F.tile_h;
     uint64_t per_batch = s->batch_paths / P;
+    if (per_batch > (uint64_t)(p->spp_end - p->spp_begin)) per_batch = p->spp_end - p->spp_begin;
     if (per_batch < 1) per_batch = 1;
+    {
+        // The queues of a batch take 144 bytes per path and lane.  Larger batches are faster (fewer thin bounce tails per
+        // frame: a 2048-spp Cornell frame +4 % at 256 Mi paths against 64 Mi), but only while they fit: samples per
+        // batch are halved until both lanes' queues fit into 3/4 of what the device has free beyond what this scene holds.
+        size_t free_b = 0, total_b = 0, held = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            for (const Lane& L : s->lane) {
+                for (const DevBuf& b : L.q) held += b.cap;
+                held += L.hits.cap + L.rad.cap + L.pre_hits.cap;
+            }
+            const uint64_t lanes = (s->overlap_below != 0 && (uint64_t)(p->spp_end - p->spp_begin) > per_batch) ? 2 : 1;
+            const double budget = 0.75 * (double)(free_b + held);
+            while (per_batch > 1 && (double)(P * per_batch) * 144.0 * 1.125 * (double)lanes > budget) per_batch = (per_batch + 1) / 2;
+        }
+    }
     const uint64_t max_paths = P * per_batch;
     if (max_paths >= 0xFFFFFFFFull) return fail(1, "render: tile has too many pixels for one batch");
 
