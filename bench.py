@@ -186,6 +186,9 @@ def main():
         scene.set_option("tail_paths", args.tail_paths)
     if args.overlap_below >= 0:
         scene.set_option("overlap_below", args.overlap_below)
+    if args.share_device and world > 1:     # rehearsal: the ranks share one GPU's memory
+        scene.set_option("batch_paths", max(1 << 22, (64 << 20) // world))
+        scene.set_option("overlap_below", 4 << 20)
     accums = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
     pending = [None] * len(accums)
     spp = args.spp
