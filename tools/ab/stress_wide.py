@@ -42,7 +42,9 @@ def main():
             nr = nr / nr.norm(dim=1, keepdim=True).clamp_min(1e-30)
             return p, nr
 
-        kinds = {"surface to surface": 0, "surface, random direction": 0, "across the box": 0}
+        kinds = {"surface to surface": 0, "surface, random direction": 0, "across the box": 0, "grazing": 0}
+        if os.environ.get("STRESS_KINDS"):
+            kinds = {k: 0 for k in os.environ["STRESS_KINDS"].split(",")}
         t0 = time.time()
         for r in range(rounds):
             for kind in kinds:
@@ -50,6 +52,24 @@ def main():
                     c = (lo + hi) / 2; ext = (hi - lo).max()
                     o = c + (torch.rand((n, 3), device="cuda", generator=g) - 0.5) * ext * 2.5
                     d = lo + torch.rand((n, 3), device="cuda", generator=g) * (hi - lo) - o
+                elif kind == "grazing":
+                    # rays that run along a triangle's plane at a slope between 1e-8 and 1e-2, through a point of the
+                    # triangle or just beside it, from a point up to a few scene sizes back: where a triangle test's
+                    # t, u, v are worst conditioned
+                    pick = torch.randint(0, len(tris), (n,), device="cuda", generator=g)
+                    tp = tris[pick]
+                    e1 = tp[:, 1] - tp[:, 0]; e2 = tp[:, 2] - tp[:, 0]
+                    nr = torch.linalg.cross(e1, e2); nr = nr / nr.norm(dim=1, keepdim=True).clamp_min(1e-30)
+                    a = torch.rand(n, device="cuda", generator=g) * 1.4 - 0.2; b = torch.rand(n, device="cuda", generator=g) * 1.4 - 0.2
+                    p = tp[:, 0] + a[:, None] * e1 + b[:, None] * e2
+                    ang = torch.rand(n, device="cuda", generator=g) * 6.2831853
+                    u1 = e1 / e1.norm(dim=1, keepdim=True).clamp_min(1e-30); u2 = torch.linalg.cross(nr, u1)
+                    inplane = torch.cos(ang)[:, None] * u1 + torch.sin(ang)[:, None] * u2
+                    slope = 10.0 ** (-8.0 + 6.0 * torch.rand(n, device="cuda", generator=g)) * (torch.randint(0, 2, (n,), device="cuda", generator=g) * 2 - 1)
+                    d = inplane + slope[:, None] * nr
+                    back = (hi - lo).max() * 10.0 ** (-2.0 + 2.5 * torch.rand(n, device="cuda", generator=g))
+                    o = p - back[:, None] * d
+                    d = d * 10.0 ** (-1.0 + 2.0 * torch.rand(n, device="cuda", generator=g))[:, None]
                 else:
                     p, nr = surface_points(n)
                     o = p + 1e-3 * nr
