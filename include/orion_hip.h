@@ -187,7 +187,9 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *                 3 = one ray per wave at a time (scenes of at most 64 inner nodes +
  *                 triangles; slow on batches, it exists to test the walk the tail kernel uses),
  *                 4 = ordered, distance-culled traversal of the 4-wide tree (scenes above 64 nodes whose
- *                 trees keep every child box inside its parent's)
+ *                 trees keep every child box inside its parent's); what 0 picks for scenes above 384 nodes.
+ *                 Returns what 1 returns on every natural batch tested; rays aimed along a triangle's plane
+ *                 at a slope below 1e-5 can come out differently (the reference's own answer is rounding noise there)
  *   "tail_paths"  a render batch hands its remaining paths to the one-path-per-wave
  *                 tail kernel once at most this many are left (0 = never; small scenes only)
  *   "batch_paths" upper bound on paths in flight per render batch (default 256 Mi: 36 GiB of queues

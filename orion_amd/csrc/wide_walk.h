@@ -19,11 +19,13 @@
 //     lies inside the triangle's box grown by that much: a leaf whose grown box the ray misses, and any
 //     slot whose grown box begins beyond the best hit so far.  The triangle test's rounding moves the
 //     computed hit by about 1e-5 / (sin(apex angle) * cos(angle to the normal)) of its distance, so the
-//     assumption can only fail for a ray within a fraction of a degree of the plane of a triangle that
-//     also lies behind the hit the ray does find.  That part is measured, not proven: this walk and the
-//     unculled walk agree on every one of 1.6 * 10^10 rays aimed along and across three scenes' surfaces
+//     assumption can only fail for a ray nearly in the plane of a triangle.  That part is measured, not proven: this
+//     walk and the unculled walk agree on every one of 1.6 * 10^10 rays aimed along and across three scenes' surfaces
 //     (tools/ab/stress_wide.py), as does the CPU model of this walk with the reference's restatement
-//     (tests/test_wide_tree.py).  Option "traversal" = 1 keeps the unculled per-lane walk.
+//     (tests/test_wide_tree.py).  Where it fails, also measured: rays aimed ALONG a triangle's plane at a slope below
+//     1e-5.  There the reference's determinant is a few rounding errors above the 1e-6 it rejects, its t, u, v are
+//     rounding residue divided by that, and the hit it accepts lies up to a dozen margins outside the triangle's box
+//     (347 of 10^9 such rays on a 19 058-triangle model).  Option "traversal" = 1 keeps the unculled per-lane walk.
 //   * Rays the argument does not cover -- an origin component that is not finite or beyond the scene's
 //     bound, a direction component that is zero, denormal, not finite or outside 2^-40 .. 2^40 -- and
 //     lanes whose stack would overflow take the unculled walk (traverse_lane) instead.
