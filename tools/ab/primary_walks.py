@@ -29,3 +29,14 @@ for mode in (2, 4):
     for _ in range(5): sc.closest_hit(to2, td2, out2)
     st = sc.profile_read()['closest_hit']; sc.profile(False)
     print('mode', mode, 'hitting waves only', len(to2), 'rays', round(st['ms']/5,3), 'ms', round(5*len(to2)/st['ms']/1e3), 'Mrays/s')
+# ... and many samples of them in one batch (a frame's batch holds 32 samples per pixel): is the launch of 0.3 M rays above just short?
+rep = 16
+jit = (torch.rand((rep, 1, 3), device='cuda') - 0.5) * 2e-4
+to3 = to2.unsqueeze(0).expand(rep, -1, -1).reshape(-1, 3).contiguous()
+td3 = (td2.unsqueeze(0) + jit).reshape(-1, 3).contiguous(); out3 = torch.empty((len(to3),5), dtype=torch.int32, device='cuda')
+for mode in (2, 4, 0):
+    sc.set_option('traversal', mode)
+    sc.closest_hit(to3, td3, out3); sc.profile(True)
+    for _ in range(5): sc.closest_hit(to3, td3, out3)
+    st = sc.profile_read()['closest_hit']; sc.profile(False)
+    print('mode', mode, 'hitting waves x', rep, len(to3), 'rays', round(st['ms']/5,3), 'ms', round(5*len(to3)/st['ms']/1e3), 'Mrays/s')
