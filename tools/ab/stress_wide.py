@@ -44,7 +44,7 @@ def main():
 
         kinds = {"surface to surface": 0, "surface, random direction": 0, "across the box": 0, "grazing": 0}
         if os.environ.get("STRESS_KINDS"):
-            kinds = {k: 0 for k in os.environ["STRESS_KINDS"].split(",")}
+            kinds = {k: 0 for k in os.environ["STRESS_KINDS"].split(";")}   # (one kind has a comma in its name)
         t0 = time.time()
         for r in range(rounds):
             for kind in kinds:
