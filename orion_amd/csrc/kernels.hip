@@ -116,6 +116,7 @@ struct OrionScene {
     uint64_t batch_paths = 256u << 20;    // paths in flight per batch (128 B of queues each; less where the device's free memory asks for it)
     uint32_t overlap_below = 32u << 20;   // start the next batch on the other lane once this few rays are left (0: never)
     uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
+    uint64_t queue_budget = 0;            // bytes the render queues may take (0: three quarters of the device's free memory)
     bool draw_rays = true;                // large scenes: bounce rays are handed to lanes as they finish (k_extend_wide)
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
@@ -685,6 +686,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
         s->draw_rays = value != 0;
         return 0;
     }
+    if (!std::strcmp(name, "queue_budget_mib")) {
+        if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: queue_budget_mib out of range");
+        s->queue_budget = (uint64_t)value << 20;
+        return 0;
+    }
     if (!std::strcmp(name, "fail_at_bounce")) {
         if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: fail_at_bounce out of range");
         s->fail_at_bounce = (uint32_t)value;
@@ -806,7 +812,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                 held += L.hits.cap + L.rad.cap + L.pre_hits.cap;
             }
             const uint64_t lanes = (s->overlap_below != 0 && (uint64_t)(p->spp_end - p->spp_begin) > per_batch) ? 2 : 1;
-            const double budget = 0.75 * (double)(free_b + held);
+            const double budget = s->queue_budget ? (double)s->queue_budget : 0.75 * (double)(free_b + held);
             while (per_batch > 1 && (double)(P * per_batch) * 144.0 * 1.125 * (double)lanes > budget) per_batch = (per_batch + 1) / 2;
         }
     }

@@ -669,3 +669,20 @@ def test_two_lanes_change_nothing(gpu):
     pimg = sc.render(cam, W, H, 0, 8, 1, 6, seed=5, lights=lights)
     assert np.array_equal(bits(pref), bits(pimg))
     sc.close()
+
+
+def test_a_small_queue_budget_changes_nothing(gpu):
+    """A render call sizes its batches to the memory it may take (option queue_budget_mib; by default three
+    quarters of the device's free memory): with room for a few samples per batch only, the image keeps its bits."""
+    import torch
+    sc = scene_for(gpu, "cornell")
+    cam = gpu.camera_vectors([-0.10141, 1, 3.00498], [-0.10141, 1, 2.00498], [0, 1, 0], 1.0, 16 / 9)
+    W, H = 480, 270
+    ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    sc.render(cam, W, H, 0, 48, 2, 12, seed=3, accum=ref)
+    for mib in (64, 40):      # 144 B per path and lane: 64 MiB hold one batch of 3 samples per lane, 40 MiB one of 2
+        sc.set_option("queue_budget_mib", mib)
+        acc = torch.zeros_like(ref)
+        sc.render(cam, W, H, 0, 48, 2, 12, seed=3, accum=acc)
+        assert torch.equal(acc, ref), mib
+    sc.set_option("queue_budget_mib", 0)
