@@ -307,7 +307,7 @@ def main():
                                "per_sample": rays / (W * H * 128),
                                "Mrays_per_s_per_gpu": rays / (W * H * 128) * value / world / 1e6,
                                "note": "closest-hit queries per pixel-sample (profiled pass) x the timed region's samples/s per GPU"}
-        if not args.no_ray_batches:
+        if world == 1 and not args.no_ray_batches:      # (single-GPU figures: the other ranks would only wait for them)
             out["ray_batches"] = ray_batches(api)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cb = cpu_baseline(model, cam)
