@@ -35,6 +35,9 @@ static_assert(kBlock == kWideBlock, "the wide walk's stack is laid out for this 
 // MODE_WIDE: every lane walks the 4-wide tree, nearest first, with distance culling (wide_walk.h);
 // MODE_ADAPT_WIDE: MODE_ADAPT with that walk for the waves that are not coherent.
 // MODE_PRE (k_extend only): the closest hits were found by k_extend_wide before the launch; k_extend just takes them.
+#ifndef ORION_EXPERIMENT_NO_RAD
+#define ORION_EXPERIMENT_NO_RAD 0
+#endif
 enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4, MODE_WIDE = 5, MODE_ADAPT_WIDE = 6, MODE_PRE = 7 };
 
 // True for every lane of a wave whose active rays share their origin exactly and lie within about
@@ -749,11 +752,23 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
             color = color + contrib * inv_ls;
         }
         if (live) {
+#if ORION_EXPERIMENT_NO_RAD == 1
+            if (writer && color.x == 12345.0f) rad[pid] = make_float4(color.x, 0.0f, 0.0f, 0.0f);   // timing experiment: no radiance traffic
+#elif ORION_EXPERIMENT_NO_RAD == 2
+            if (writer) { const V3 acc = T * color; rad[blockIdx.x * kBlock + threadIdx.x] = make_float4(acc.x, acc.y, acc.z, 0.0f); }   // timing experiment: coalesced write, no read
+#elif ORION_EXPERIMENT_NO_RAD == 3
+            if (writer) {   // timing experiment: three hardware float atomics, nothing to wait for
+                const V3 acc = T * color;
+                float* rp = reinterpret_cast<float*>(rad + pid);
+                unsafeAtomicAdd(rp, acc.x); unsafeAtomicAdd(rp + 1, acc.y); unsafeAtomicAdd(rp + 2, acc.z);
+            }
+#else
             if (writer) {
                 const float4 r0 = rad[pid];
                 const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
                 rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
             }
+#endif
             if (depth < F.max_depth) {
                 // Russian roulette on max(kd), then a cosine-weighted direction (orion/raytracer.cpp:164-194)
                 const float cc = tpl_max(tpl_max(kd.x, kd.y), kd.z);
