@@ -811,9 +811,12 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                 for (const DevBuf& b : L.q) held += b.cap;
                 held += L.hits.cap + L.rad.cap + L.pre_hits.cap;
             }
-            const uint64_t lanes = (s->overlap_below != 0 && (uint64_t)(p->spp_end - p->spp_begin) > per_batch) ? 2 : 1;
             const double budget = s->queue_budget ? (double)s->queue_budget : 0.75 * (double)(free_b + held);
-            while (per_batch > 1 && (double)(P * per_batch) * 144.0 * 1.125 * (double)lanes > budget) per_batch = (per_batch + 1) / 2;
+            auto need = [&](uint64_t spb) {   // both lanes' queues once the call has more than one batch
+                const double lanes = (s->overlap_below != 0 && (uint64_t)(p->spp_end - p->spp_begin) > spb) ? 2.0 : 1.0;
+                return (double)(P * spb) * 144.0 * 1.125 * lanes;
+            };
+            while (per_batch > 1 && need(per_batch) > budget) per_batch = (per_batch + 1) / 2;
         }
     }
     const uint64_t max_paths = P * per_batch;
