@@ -242,7 +242,7 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
 // paths, which for scenes of a few dozen nodes is close to every lane's own path.
 // Must be entered by all lanes that want a result; `active` = false lanes idle.
 // ---------------------------------------------------------------------------
-template <bool QUICK_DIV>
+template <bool QUICK_DIV, bool AHEAD>
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast);
 // Closest hit only.  A point-light shadow query ("is anything hit at t >= 0") is answered by the
 // same walk: a triangle is accepted against t = +inf under exactly the any-hit condition, and later
@@ -258,8 +258,26 @@ __device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, Hi
     const uint32_t next = active ? 0u : kInvalid;
     const uint32_t ufast = __builtin_amdgcn_readfirstlane(fast ? 1u : 0u);
     if (S.n_nodes && __any(active)) {   // (the walk relies on a lane being there to follow)
-        if (quick_det) traverse_wave_closest_asm<true>(S, o, d, inv, h, next, ufast);
-        else traverse_wave_closest_asm<false>(S, o, d, inv, h, next, ufast);
+        if (quick_det) traverse_wave_closest_asm<true, false>(S, o, d, inv, h, next, ufast);
+        else traverse_wave_closest_asm<false, false>(S, o, d, inv, h, next, ufast);
+    }
+}
+
+// The same walk for trees of thousands of nodes, whose records come from the L2 (the scalar cache holds a few hundred):
+// there the loop waits for its scalar loads more than it computes (camera rays on a 13 k-node model: the waves of the
+// first bounce spend 0.7 of their cycles waiting), and its AHEAD form asks for the next record in array order while it
+// tests the present one (see ORION_NODE_FETCH_AHEAD below).  Same operations, same bits.
+__device__ __forceinline__ void traverse_wave_ahead(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
+    bool d_small, d_normal;
+    dir_class(d, S.dir_bound, d_small, d_normal);
+    const bool quick_det = __all(!active || d_small), quick_inv = __all(!active || d_normal);   // wave-uniform
+    const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
+    const bool fast = quick_inv ? __all(!active || finite3(o)) : __all(!active || slab_safe(o, inv));
+    const uint32_t next = active ? 0u : kInvalid;
+    const uint32_t ufast = __builtin_amdgcn_readfirstlane(fast ? 1u : 0u);
+    if (S.n_nodes && __any(active)) {
+        if (quick_det) traverse_wave_closest_asm<true, true>(S, o, d, inv, h, next, ufast);
+        else traverse_wave_closest_asm<false, true>(S, o, d, inv, h, next, ufast);
     }
 }
 
@@ -371,17 +389,39 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 // checks it and never selects this walk for a larger scene.  SGPRs s52-s63 hold the
 // node or triangle being processed.
 // ---------------------------------------------------------------------------
-#define ORION_WALK_BEFORE_DIV \
+/* How a node's record gets into s52-s59.  PLAIN: load it and wait.  AHEAD (trees of thousands of nodes, whose records come \
+   from the L2: the walk then waits for its loads more than it computes): the record behind the present one in array order \
+   -- where the walk goes from a leaf and from an inner node that a lane enters -- was asked for a node ago into s64-s71 \
+   and is copied over; a jump to a skip link loads afresh.  The request for the next record goes out right after the wait, \
+   so it is under way while this node is tested (the node array carries one spare record at its end). */ \
+#define ORION_NODE_FETCH_PLAIN \
+        "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n"  /* lo.xyz a | hi.xyz b */ \
+        "s_waitcnt lgkmcnt(0)\n"
+#define ORION_NODE_INIT_PLAIN
+#define ORION_NODE_INIT_AHEAD "s_mov_b32 %[pfo], -1\n"  /* the offset the record in s64-s71 was asked from */
+#define ORION_NODE_FETCH_AHEAD \
+        "s_cmp_eq_u32 %[pfo], %[noff]\n" \
+        "s_cbranch_scc1 L_have%=\n" \
+        "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "s_branch L_go%=\n" \
+        "L_have%=:\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "s_mov_b64 s[52:53], s[64:65]\n s_mov_b64 s[54:55], s[66:67]\n s_mov_b64 s[56:57], s[68:69]\n s_mov_b64 s[58:59], s[70:71]\n" \
+        "L_go%=:\n" \
+        "s_add_u32 %[pfo], %[noff], 32\n" \
+        "s_load_dwordx8 s[64:71], %[nodes], %[pfo]\n"
+#define ORION_WALK_BEFORE_DIV(NODE_FETCH_INIT, NODE_FETCH) \
         "s_mov_b64 %[EX], exec\n" \
         "s_mov_b32 %[noff], 0\n"  /* byte offset of the node, steps by 32; the lanes' `next` is kept in the same unit */ \
+        NODE_FETCH_INIT \
         "s_lshl_b32 %[nend], %[nn], 5\n" \
         "v_lshlrev_b32 %[nx], 5, %[nx]\n"  /* (kInvalid stays out of range) */ \
         "s_mov_b32 %[eps], 0x358637bd\n"  /* 1e-6f */ \
         "L_node%=:\n" \
         /* the lanes at this node: never none -- the walk only moves to where the lane furthest behind waits */ \
         "v_cmp_eq_u32_e64 %[MI], %[noff], %[nx]\n" \
-        "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n"  /* lo.xyz a | hi.xyz b */ \
-        "s_waitcnt lgkmcnt(0)\n" \
+        NODE_FETCH \
         "s_bitcmp1_b32 s59, 31\n"                                                                           \
         "s_cbranch_scc1 L_leaf%=\n"                                                                         \
         /* ---- inner node: slab test, next = in ? node + 1 : skip */                                       \
@@ -549,9 +589,10 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "L_test%=:\n" \
         "s_cmp_lt_u32 %[noff], %[nend]\n" \
         "s_cbranch_scc1 L_node%=\n" \
+        "s_waitcnt lgkmcnt(0)\n"  /* (AHEAD: the last request must have landed before s64-s71 are anyone else's) */ \
         "s_mov_b64 exec, %[EX]\n"                                                       
-#define ORION_WALK_OPERANDS \
-        : [nx] "+v"(next), [ht] "+v"(ht), [hu] "+v"(hu), [hv] "+v"(hv), [hg] "+v"(hg),                                          \
+#define ORION_WALK_OPERANDS(EXTRA_OUT) \
+        : EXTRA_OUT [nx] "+v"(next), [ht] "+v"(ht), [hu] "+v"(hu), [hv] "+v"(hv), [hg] "+v"(hg),                                          \
           [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [det] "=&v"(det), [idet] "=&v"(idet),                                 \
           [tx] "=&v"(tx), [ty] "=&v"(ty), [tz] "=&v"(tz),                                                                       \
           [aa] "=&v"(aa), [bb] "=&v"(bb), [cc] "=&v"(cc), [uu] "=&v"(uu), [du] "=&v"(du), [dv] "=&v"(dv), [dt] "=&v"(dt),       \
@@ -560,9 +601,13 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         : [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z),                             \
           [ix] "v"(inv.x), [iy] "v"(inv.y), [iz] "v"(inv.z),                                                                    \
           [nodes] "s"(S.nodes), [tris] "s"(S.tris), [nn] "s"(S.n_nodes), [fast] "s"(fast)                                       \
-        : "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc");                   
+        : "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc"
+#define ORION_WALK_OUT_PLAIN
+#define ORION_WALK_OUT_AHEAD [pfo] "=&s"(pfo),
+#define ORION_WALK_CLOBBER_PLAIN );
+#define ORION_WALK_CLOBBER_AHEAD , "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71");
 
-template <bool QUICK_DIV>
+template <bool QUICK_DIV, bool AHEAD>
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast) {
     float ht = h.t, hu = h.u, hv = h.v;
     uint32_t hg = h.gtri;
@@ -570,10 +615,16 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
     float px, py, pz, det, idet, tx, ty, tz, aa, bb, cc, uu, du, dv, dt;
     // SGPR temporaries: EX = lanes that entered, MI = lanes at the current node, PM = a stage's verdict
     unsigned long long EX, MI, PM;
-    uint32_t noff, nend, toff, cnt, eps;
+    uint32_t noff, nend, toff, cnt, eps, pfo;
     fast = __builtin_amdgcn_readfirstlane(fast);
-    if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS
-    else asm volatile(ORION_WALK_BEFORE_DIV ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS
+    if (AHEAD) {
+        if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_AHEAD, ORION_NODE_FETCH_AHEAD) ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS(ORION_WALK_OUT_AHEAD) ORION_WALK_CLOBBER_AHEAD
+        else asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_AHEAD, ORION_NODE_FETCH_AHEAD) ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS(ORION_WALK_OUT_AHEAD) ORION_WALK_CLOBBER_AHEAD
+    } else {
+        if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_PLAIN, ORION_NODE_FETCH_PLAIN) ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS(ORION_WALK_OUT_PLAIN) ORION_WALK_CLOBBER_PLAIN
+        else asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_PLAIN, ORION_NODE_FETCH_PLAIN) ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS(ORION_WALK_OUT_PLAIN) ORION_WALK_CLOBBER_PLAIN
+    }
+    (void)pfo;
     h.t = ht; h.u = hu; h.v = hv; h.gtri = hg;
 }
 
@@ -582,5 +633,13 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
 #undef ORION_WALK_DIV_QUICK
 #undef ORION_WALK_AFTER_DIV
 #undef ORION_WALK_OPERANDS
+#undef ORION_WALK_CLOBBER_PLAIN
+#undef ORION_WALK_OUT_PLAIN
+#undef ORION_WALK_OUT_AHEAD
+#undef ORION_WALK_CLOBBER_AHEAD
+#undef ORION_NODE_FETCH_PLAIN
+#undef ORION_NODE_FETCH_AHEAD
+#undef ORION_NODE_INIT_PLAIN
+#undef ORION_NODE_INIT_AHEAD
 
 } // namespace orion_dev

@@ -118,6 +118,7 @@ struct OrionScene {
     uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
     uint64_t queue_budget = 0;            // bytes the render queues may take (0: three quarters of the device's free memory)
     bool draw_rays = true;                // large scenes: bounce rays are handed to lanes as they finish (k_extend_wide)
+    bool wave_ahead = true;               // large scenes: the primary rays' wave-synchronous walk fetches one record ahead
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
     DevBuf s_work;                    // grab counter + chunk list of the large-scene ray queries
@@ -592,8 +593,13 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     if (hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming) != hipSuccess) { s->ev_upload = nullptr; return bail(fail(2, "hipEventCreate failed")); }
     SceneView& v = s->view;
     int rc = 0;
+    v.n_nodes = (uint32_t)nodes.size(); v.n_tris = (uint32_t)tris.size();
+    // One spare record behind each array: the walk that asks for the next node ahead of time (traverse_wave_ahead)
+    // reads one past the node it is at.
+    nodes.push_back(Node{}); tris.push_back(Tri{});
     if ((rc = upload(s, nodes, &v.nodes))) return bail(rc);
     if ((rc = upload(s, tris, &v.tris))) return bail(rc);
+    nodes.pop_back(); tris.pop_back();
     if ((rc = upload(s, attrs, &v.attrs))) return bail(rc);
     if ((rc = upload(s, slot_of, &v.slot_of))) return bail(rc);
     if ((rc = upload(s, dmeshes, &v.meshes))) return bail(rc);
@@ -686,6 +692,7 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
         s->draw_rays = value != 0;
         return 0;
     }
+    if (!std::strcmp(name, "wave_ahead")) { s->wave_ahead = value != 0; return 0; }
     if (!std::strcmp(name, "queue_budget_mib")) {
         if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: queue_budget_mib out of range");
         s->queue_budget = (uint64_t)value << 20;
@@ -915,7 +922,11 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             // scenes of any size.  (The shadow rays a point-light frame casts from their hit points do
             // not: measured on the 38 k-node nanosuit frame, the per-lane walk is 25 % faster on those.)
             const bool coherent = depth == 0 && per_lane && s->traversal == 0 && s->wave_ok;
-            with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
+            if (coherent && s->wave_ahead) {
+                // ... in its form that fetches the next record while it tests the present one: in a tree of thousands of
+                // nodes the walk waits for its scalar loads (they come from the L2), not for the vector ALU.
+                if (wide) extend(k_extend<MODE_WAVE_AHEAD, kRaysWide, true>); else extend(k_extend<MODE_WAVE_AHEAD, 1, true>);
+            } else with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
                 constexpr int MODE = decltype(M)::value;
                 if (depth == 0) {   // primary rays are generated inside the launch
                     if (wide) extend(k_extend<MODE, kRaysWide, true>); else extend(k_extend<MODE, 1, true>);

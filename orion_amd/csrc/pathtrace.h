@@ -38,7 +38,8 @@ static_assert(kBlock == kWideBlock, "the wide walk's stack is laid out for this 
 #ifndef ORION_EXPERIMENT_NO_RAD
 #define ORION_EXPERIMENT_NO_RAD 0
 #endif
-enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4, MODE_WIDE = 5, MODE_ADAPT_WIDE = 6, MODE_PRE = 7 };
+// MODE_WAVE_AHEAD: MODE_WAVE through the walk that fetches one record ahead (traverse_wave_ahead; trees of thousands of nodes).
+enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4, MODE_WIDE = 5, MODE_ADAPT_WIDE = 6, MODE_PRE = 7, MODE_WAVE_AHEAD = 8 };
 
 // True for every lane of a wave whose active rays share their origin exactly and lie within about
 // 25 degrees of the first active ray's direction.
@@ -57,6 +58,8 @@ template <int MODE, bool ANY>
 __device__ __forceinline__ void traverse(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
     if (MODE == MODE_WAVE) {
         traverse_wave(S, o, d, h, active);   // (answers any-hit queries too, see there)
+    } else if (MODE == MODE_WAVE_AHEAD) {
+        traverse_wave_ahead(S, o, d, h, active);
     } else if (MODE == MODE_ADAPT) {
         if (wave_is_coherent(o, d, active)) traverse_wave(S, o, d, h, active);
         else if (active) traverse_lane<ANY>(S, o, d, h);
@@ -564,7 +567,10 @@ __device__ __forceinline__ void primary_ray_tile(const FrameParams& F, const Til
 // launch time is one thread's serial work and more blocks are the only way to shorten it.
 constexpr uint32_t kRaysWide = 4;
 constexpr uint32_t kTileWide = kBlock * kRaysWide;
-constexpr uint32_t kNarrowBelow = 1u << 21;   // rays; about one ray per thread slot of the chip x 4
+#ifndef ORION_NARROW_BELOW
+#define ORION_NARROW_BELOW (1u << 21)
+#endif
+constexpr uint32_t kNarrowBelow = ORION_NARROW_BELOW;   // rays; about one ray per thread slot of the chip x 4
 constexpr uint32_t kMaxBins = 64;
 
 // Closest hit of every queued ray (orion/model.hpp:52-62).  Rays that miss end here: a miss

@@ -40,3 +40,13 @@ for mode in (2, 4, 0):
     for _ in range(5): sc.closest_hit(to3, td3, out3)
     st = sc.profile_read()['closest_hit']; sc.profile(False)
     print('mode', mode, 'hitting waves x', rep, len(to3), 'rays', round(st['ms']/5,3), 'ms', round(5*len(to3)/st['ms']/1e3), 'Mrays/s')
+# ... and the whole frame's rays, sixteen samples in one batch, as the first bounce of a render batch holds them
+jit = (torch.rand((rep, 1, 3), device='cuda') - 0.5) * 2e-4
+to4 = to.unsqueeze(0).expand(rep, -1, -1).reshape(-1, 3).contiguous()
+td4 = (td.unsqueeze(0) + jit).reshape(-1, 3).contiguous(); out4 = torch.empty((len(to4),5), dtype=torch.int32, device='cuda')
+for mode in (2,):
+    sc.set_option('traversal', mode)
+    sc.closest_hit(to4, td4, out4); sc.profile(True)
+    for _ in range(5): sc.closest_hit(to4, td4, out4)
+    st = sc.profile_read()['closest_hit']; sc.profile(False)
+    print('mode', mode, 'whole frame x', rep, len(to4), 'rays', round(st['ms']/5,3), 'ms', round(5*len(to4)/st['ms']/1e3), 'Mrays/s')
