@@ -397,6 +397,31 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 #define ORION_NODE_FETCH_PLAIN \
         "s_load_dwordx8 s[52:59], %[nodes], %[noff]\n"  /* lo.xyz a | hi.xyz b */ \
         "s_waitcnt lgkmcnt(0)\n"
+/* ... and a leaf's triangles into s52-s63.  AHEAD: while a triangle is tested the next one of the leaf is on its way into \
+   s72-s83 (the triangle array carries one spare record as well, though the look-ahead never leaves the leaf). */ \
+#define ORION_TRI_FETCH_PLAIN \
+        "L_tri%=:\n" \
+        "s_load_dwordx8 s[52:59], %[tris], %[toff]\n"  /* v0.xyz gtri e1.xyz */ \
+        "s_load_dwordx4 s[60:63], %[tris], %[toff] offset:0x20\n"  /* e2.xyz */ \
+        "s_add_u32 %[toff], %[toff], 48\n" \
+        "s_waitcnt lgkmcnt(0)\n"
+#define ORION_TRI_NEXT_PLAIN \
+        "s_cbranch_scc1 L_tri%=\n"
+#define ORION_TRI_FETCH_AHEAD \
+        ORION_TRI_FETCH_PLAIN \
+        "L_tri_go%=:\n"  /* s52-s63 hold the triangle, toff is the offset of the one after it */ \
+        "s_cmp_lt_u32 %[toff], %[cnt]\n" \
+        "s_cbranch_scc0 L_tri_test%=\n" \
+        "s_load_dwordx8 s[72:79], %[tris], %[toff]\n" \
+        "s_load_dwordx4 s[80:83], %[tris], %[toff] offset:0x20\n" \
+        "L_tri_test%=:\n"
+#define ORION_TRI_NEXT_AHEAD \
+        "s_cbranch_scc0 L_leaf_done%=\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "s_mov_b64 s[52:53], s[72:73]\n s_mov_b64 s[54:55], s[74:75]\n s_mov_b64 s[56:57], s[76:77]\n" \
+        "s_mov_b64 s[58:59], s[78:79]\n s_mov_b64 s[60:61], s[80:81]\n s_mov_b64 s[62:63], s[82:83]\n" \
+        "s_add_u32 %[toff], %[toff], 48\n" \
+        "s_branch L_tri_go%=\n"
 #define ORION_NODE_INIT_PLAIN
 #define ORION_NODE_INIT_AHEAD "s_mov_b32 %[pfo], -1\n"  /* the offset the record in s64-s71 was asked from */
 #define ORION_NODE_FETCH_AHEAD \
@@ -411,7 +436,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "L_go%=:\n" \
         "s_add_u32 %[pfo], %[noff], 32\n" \
         "s_load_dwordx8 s[64:71], %[nodes], %[pfo]\n"
-#define ORION_WALK_BEFORE_DIV(NODE_FETCH_INIT, NODE_FETCH) \
+#define ORION_WALK_BEFORE_DIV(NODE_FETCH_INIT, NODE_FETCH, TRI_FETCH) \
         "s_mov_b64 %[EX], exec\n" \
         "s_mov_b32 %[noff], 0\n"  /* byte offset of the node, steps by 32; the lanes' `next` is kept in the same unit */ \
         NODE_FETCH_INIT \
@@ -483,11 +508,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "s_mul_i32 %[cnt], %[cnt], 48\n" \
         "s_add_u32 %[cnt], %[cnt], %[toff]\n"  /* ... and of the end of its last */ \
         "s_and_b64 exec, %[EX], %[MI]\n" \
-        "L_tri%=:\n" \
-        "s_load_dwordx8 s[52:59], %[tris], %[toff]\n"  /* v0.xyz gtri e1.xyz */ \
-        "s_load_dwordx4 s[60:63], %[tris], %[toff] offset:0x20\n"  /* e2.xyz */ \
-        "s_add_u32 %[toff], %[toff], 48\n" \
-        "s_waitcnt lgkmcnt(0)\n" \
+        TRI_FETCH \
         /* pvec = cross(d, e2) */                                                                           \
         "v_mul_f32 %[px], s62, %[dy]\n"                                                                     \
         "v_mul_f32 %[py], s60, %[dz]\n"                                                                     \
@@ -530,7 +551,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "v_subrev_f32 %[tz], s54, %[oz]\n"                                               \
         "v_fma_f32 %[aa], -%[det], %[bb], 1.0\n" \
         "v_fma_f32 %[idet], %[aa], %[bb], %[bb]\n"
-#define ORION_WALK_AFTER_DIV \
+#define ORION_WALK_AFTER_DIV(TRI_NEXT) \
         /* u = dot(tvec, pvec) * inv_det */ \
         "v_mul_f32 %[aa], %[tx], %[px]\n"                                                \
         "v_mul_f32 %[bb], %[ty], %[py]\n"                                                \
@@ -579,7 +600,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
         "L_tri_next%=:\n"                                                                \
         "s_and_b64 exec, %[EX], %[MI]\n" \
         "s_cmp_lt_u32 %[toff], %[cnt]\n" \
-        "s_cbranch_scc1 L_tri%=\n" \
+        TRI_NEXT \
         "L_leaf_done%=:\n"                                                               \
         "s_mov_b64 exec, %[EX]\n" \
         "v_add_u32_e64 %[bb], %[noff], 32\n" \
@@ -605,7 +626,7 @@ __device__ __forceinline__ void traverse_one_each(const SceneView& S, V3 o, V3 d
 #define ORION_WALK_OUT_PLAIN
 #define ORION_WALK_OUT_AHEAD [pfo] "=&s"(pfo),
 #define ORION_WALK_CLOBBER_PLAIN );
-#define ORION_WALK_CLOBBER_AHEAD , "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71");
+#define ORION_WALK_CLOBBER_AHEAD , "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83");
 
 template <bool QUICK_DIV, bool AHEAD>
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast) {
@@ -618,11 +639,11 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
     uint32_t noff, nend, toff, cnt, eps, pfo;
     fast = __builtin_amdgcn_readfirstlane(fast);
     if (AHEAD) {
-        if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_AHEAD, ORION_NODE_FETCH_AHEAD) ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS(ORION_WALK_OUT_AHEAD) ORION_WALK_CLOBBER_AHEAD
-        else asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_AHEAD, ORION_NODE_FETCH_AHEAD) ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS(ORION_WALK_OUT_AHEAD) ORION_WALK_CLOBBER_AHEAD
+        if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_AHEAD, ORION_NODE_FETCH_AHEAD, ORION_TRI_FETCH_AHEAD) ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV(ORION_TRI_NEXT_AHEAD) ORION_WALK_OPERANDS(ORION_WALK_OUT_AHEAD) ORION_WALK_CLOBBER_AHEAD
+        else asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_AHEAD, ORION_NODE_FETCH_AHEAD, ORION_TRI_FETCH_AHEAD) ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV(ORION_TRI_NEXT_AHEAD) ORION_WALK_OPERANDS(ORION_WALK_OUT_AHEAD) ORION_WALK_CLOBBER_AHEAD
     } else {
-        if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_PLAIN, ORION_NODE_FETCH_PLAIN) ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS(ORION_WALK_OUT_PLAIN) ORION_WALK_CLOBBER_PLAIN
-        else asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_PLAIN, ORION_NODE_FETCH_PLAIN) ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV ORION_WALK_OPERANDS(ORION_WALK_OUT_PLAIN) ORION_WALK_CLOBBER_PLAIN
+        if (QUICK_DIV) asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_PLAIN, ORION_NODE_FETCH_PLAIN, ORION_TRI_FETCH_PLAIN) ORION_WALK_DIV_QUICK ORION_WALK_AFTER_DIV(ORION_TRI_NEXT_PLAIN) ORION_WALK_OPERANDS(ORION_WALK_OUT_PLAIN) ORION_WALK_CLOBBER_PLAIN
+        else asm volatile(ORION_WALK_BEFORE_DIV(ORION_NODE_INIT_PLAIN, ORION_NODE_FETCH_PLAIN, ORION_TRI_FETCH_PLAIN) ORION_WALK_DIV_EXACT ORION_WALK_AFTER_DIV(ORION_TRI_NEXT_PLAIN) ORION_WALK_OPERANDS(ORION_WALK_OUT_PLAIN) ORION_WALK_CLOBBER_PLAIN
     }
     (void)pfo;
     h.t = ht; h.u = hu; h.v = hv; h.gtri = hg;
@@ -641,5 +662,9 @@ __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3
 #undef ORION_NODE_FETCH_AHEAD
 #undef ORION_NODE_INIT_PLAIN
 #undef ORION_NODE_INIT_AHEAD
+#undef ORION_TRI_FETCH_PLAIN
+#undef ORION_TRI_FETCH_AHEAD
+#undef ORION_TRI_NEXT_PLAIN
+#undef ORION_TRI_NEXT_AHEAD
 
 } // namespace orion_dev
