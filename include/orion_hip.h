@@ -192,13 +192,15 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *                 at a slope below 1e-5 can come out differently (the reference's own answer is rounding noise there)
  *   "tail_paths"  a render batch hands its remaining paths to the one-path-per-wave
  *                 tail kernel once at most this many are left (0 = never; small scenes only)
- *   "batch_paths" upper bound on paths in flight per render batch (default 256 Mi: 36 GiB of queues
+ *   "batch_paths" upper bound on paths in flight per render batch (default 256 Mi: up to 36 GiB of queues
  *                 per stream; a render call takes fewer where the device's free memory asks for it)
  *   "overlap_below" a render call of several batches starts the next batch on a second
  *                 stream (with queues of its own) once the current batch has fewer rays
  *                 than this left (default 32 Mi; 0 = one batch at a time, half the memory)
  *   "draw_rays"   1 (default): on scenes that walk the 4-wide tree, the closest hits of bounce rays are found
  *                 by waves that draw rays from the queue as their lanes finish; 0: four rays per thread
+ *   "wave_ahead"  1 (default): the wave-synchronous walk of a large scene's camera rays asks for the next node
+ *                 and the next triangle of a leaf while it tests the present one; 0: it fetches each when it gets there
  *   "queue_budget_mib" memory a render call's queues may take, in MiB (0, the default: three quarters of
  *                 the device's free memory); the call halves its samples per batch until they fit
  *   "fail_at_bounce" test hook: the n-th bounce a render call launches from now on fails (once) with

@@ -635,7 +635,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         v.dir_bound = (float)(bound * (1.0 - 1e-6));
     }
     s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
-    s->wave_ok = (uint64_t)tris.size() * sizeof(Tri) < (1ull << 32) && (uint64_t)nodes.size() * sizeof(Node) < (1ull << 32);
+    s->wave_ok = (uint64_t)(tris.size() + 1) * sizeof(Tri) < (1ull << 32) && (uint64_t)(nodes.size() + 1) * sizeof(Node) < (1ull << 32);   // (+ the spare records)
     {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0 &&
@@ -692,7 +692,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
         s->draw_rays = value != 0;
         return 0;
     }
-    if (!std::strcmp(name, "wave_ahead")) { s->wave_ahead = value != 0; return 0; }
+    if (!std::strcmp(name, "wave_ahead")) {
+        if (value < 0 || value > 1) return fail(1, "set_option: wave_ahead must be 0 or 1");
+        s->wave_ahead = value != 0;
+        return 0;
+    }
     if (!std::strcmp(name, "queue_budget_mib")) {
         if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: queue_budget_mib out of range");
         s->queue_budget = (uint64_t)value << 20;
