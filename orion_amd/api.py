@@ -321,10 +321,12 @@ class Frame:
     camera12: np.ndarray
 
 
-def load_frame(rtc_path: str, load_textures: bool = True) -> Frame:
+def load_frame(rtc_path: str, load_textures: bool = True, strategy: int = host.MEDIAN) -> Frame:
+    """``strategy``: how the trees are split (host.MEDIAN, the reference's default; host.MIDDLE; host.SAH --
+    SBVH::Strategy, orion/avx/sbvh.hpp:16-42)."""
     rtc = host.parse_rtc(rtc_path)
     obj = os.path.join(os.path.dirname(rtc_path), rtc.obj_file)
-    model = host.load_model(obj, load_textures=load_textures)
+    model = host.load_model(obj, strategy=strategy, load_textures=load_textures)
     cam = camera_vectors(rtc.view_point, rtc.look_at, rtc.vector_up, rtc.y_view, rtc.aspect_ratio)
     return Frame(rtc, model, cam)
 

@@ -31,10 +31,14 @@ _models = {}
 
 
 def load_model(name: str):
-    """host.Model of a named test scene ('soup' is the synthetic triangle soup)."""
+    """host.Model of a named test scene ('soup' is the synthetic triangle soup; 'nanosuit@sah' and 'nanosuit@middle'
+    build the trees with the reference's other split strategies)."""
     from orion_amd import host
     if name not in _models:
-        if name == "soup":
+        if "@" in name:
+            base, how = name.split("@")
+            _models[name] = host.load_model(scene_path(base), strategy={"median": host.MEDIAN, "middle": host.MIDDLE, "sah": host.SAH}[how])
+        elif name == "soup":
             import raygen
             v, i = raygen.triangle_soup()
             _models[name] = host.model_from_arrays(v, i)
