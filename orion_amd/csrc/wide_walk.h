@@ -78,17 +78,21 @@ __device__ __forceinline__ void wide_pop(WideState& w, float best, uint32_t tid)
 
 __device__ __forceinline__ float vmax3_abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
+// The byte words of a node's four slots, picked per axis by the direction's sign: where the ray enters the slots' slabs
+// (the lower bounds if it runs up the axis, the upper bounds if it runs down) and where it leaves them.
+struct WideBytes { uint32_t nx, ny, nz, fx, fy, fz; };
+
 // Slot K's entry distance, or +inf if the slot is empty, missed, behind the origin or beyond
-// `best`.  The slab distances of the grown box come straight from the bytes: byte * c + l for a lower bound,
-// byte * c + u for an upper bound (wide_node_step computes c, l, u per axis).
+// `best`.  The slab distances of the grown box come straight from the bytes: byte * c + l where the ray enters the slab,
+// byte * c + u where it leaves it (wide_node_step computes c, l, u per axis).
 template <int K>
-__device__ __forceinline__ float wide_slot(const float4& C, const float4& D, V3 c, V3 l, V3 u, float best, uint32_t ref) {
-    const float t1x = fmaf(byte_of<K>(__float_as_uint(C.x)), c.x, l.x), t2x = fmaf(byte_of<K>(__float_as_uint(C.w)), c.x, u.x);
-    const float t1y = fmaf(byte_of<K>(__float_as_uint(C.y)), c.y, l.y), t2y = fmaf(byte_of<K>(__float_as_uint(D.x)), c.y, u.y);
-    const float t1z = fmaf(byte_of<K>(__float_as_uint(C.z)), c.z, l.z), t2z = fmaf(byte_of<K>(__float_as_uint(D.y)), c.z, u.z);
+__device__ __forceinline__ float wide_slot(const WideBytes& q, V3 c, V3 l, V3 u, float best, uint32_t ref) {
+    const float t1x = fmaf(byte_of<K>(q.nx), c.x, l.x), t2x = fmaf(byte_of<K>(q.fx), c.x, u.x);
+    const float t1y = fmaf(byte_of<K>(q.ny), c.y, l.y), t2y = fmaf(byte_of<K>(q.fy), c.y, u.y);
+    const float t1z = fmaf(byte_of<K>(q.nz), c.z, l.z), t2z = fmaf(byte_of<K>(q.fz), c.z, u.z);
     // "tmax >= tmin, tmax >= 0, tmin <= best" with best >= 0 is "max(tmin, 0) <= min(tmax, best)"
-    const float tmin = vmax3(vmin(t1x, t2x), vmin(t1y, t2y), vmin(t1z, t2z));
-    const float tmax = vmin(vmin3(vmax(t1x, t2x), vmax(t1y, t2y), vmax(t1z, t2z)), best);
+    const float tmin = vmax3(t1x, t1y, t1z);
+    const float tmax = vmin(vmin3(t2x, t2y, t2z), best);
     const bool hit = (ref != kWideEmpty) & (vmax(tmin, 0.0f) <= tmax);   // (&: no branch around the comparison)
     return hit ? tmin : __builtin_inff();   // (a negative tmin orders the slots that hold the origin)
 }
@@ -115,13 +119,20 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
         // farthest corner of the node's box.
         const float reach = vmax(vmax3_abs(n0.x, n1.x, n0.y), vmax3_abs(n1.y, n0.z, n1.z));
         const float g = fmaf(kWideSlack, reach, S.wide_grow0);
+        // Which of a slab's two planes the ray meets first is the sign of the direction (bytes: lower <= upper, c has the
+        // sign of inv, l and u below lie on the entry and on the exit side), so the entry and exit distances are
+        // picked per node, one word of four slots at a time, not compared per slot.
         const V3 c = mk((s1.x - s0.x) * kWideInvCells, (s1.y - s0.y) * kWideInvCells, (s1.z - s0.z) * kWideInvCells);
-        const V3 l = mk(fmaf(-g, inv.x, s0.x), fmaf(-g, inv.y, s0.y), fmaf(-g, inv.z, s0.z));
-        const V3 u = mk(fmaf(g, inv.x, s0.x), fmaf(g, inv.y, s0.y), fmaf(g, inv.z, s0.z));
-        t0 = wide_slot<0>(C, D, c, l, u, best, r0);
-        t1 = wide_slot<1>(C, D, c, l, u, best, r1);
-        t2 = wide_slot<2>(C, D, c, l, u, best, r2);
-        t3 = wide_slot<3>(C, D, c, l, u, best, r3);
+        const V3 l = mk(fmaf(-g, fabsf(inv.x), s0.x), fmaf(-g, fabsf(inv.y), s0.y), fmaf(-g, fabsf(inv.z), s0.z));
+        const V3 u = mk(fmaf(g, fabsf(inv.x), s0.x), fmaf(g, fabsf(inv.y), s0.y), fmaf(g, fabsf(inv.z), s0.z));
+        const bool ux = inv.x > 0.0f, uy = inv.y > 0.0f, uz = inv.z > 0.0f;
+        const uint32_t lx = __float_as_uint(C.x), ly = __float_as_uint(C.y), lz = __float_as_uint(C.z);
+        const uint32_t hx = __float_as_uint(C.w), hy = __float_as_uint(D.x), hz = __float_as_uint(D.y);
+        const WideBytes q = {ux ? lx : hx, uy ? ly : hy, uz ? lz : hz, ux ? hx : lx, uy ? hy : ly, uz ? hz : lz};
+        t0 = wide_slot<0>(q, c, l, u, best, r0);
+        t1 = wide_slot<1>(q, c, l, u, best, r1);
+        t2 = wide_slot<2>(q, c, l, u, best, r2);
+        t3 = wide_slot<3>(q, c, l, u, best, r3);
     }
     const float tn = vmin(vmin3(t0, t1, t2), t3);
     if (!(tn < inf)) { wide_pop(w, best, tid); return true; }
