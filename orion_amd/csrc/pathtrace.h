@@ -291,7 +291,7 @@ __device__ __forceinline__ bool wide_share(WideState& w, V3& o, V3& d, V3& inv, 
         h.t = __uint_as_float(g_wide_ref[6][tid]); h.u = __uint_as_float(g_wide_ref[7][tid]); h.v = __uint_as_float(g_wide_ref[8][tid]);
         h.gtri = g_wide_ref[9][tid]; w.best_slot = g_wide_ref[10][tid];
         const uint32_t ref = g_wide_ref[11][tid], x = g_wide_ref[12][tid];
-        inv = ray_inverse(d);
+        inv = ray_inverse_quick(d);   // (a ray the wide walk has taken: see below)
         quick_det = (x >> 16 & 1u) != 0u;
         owner = x >> 17;
         w.sp = 0u;
@@ -405,7 +405,9 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
                     bool d_small, d_normal;
                     dir_class(d, S.dir_bound, d_small, d_normal);
                     quick_det = d_small;
-                    inv = ray_inverse(d);
+                    // Only rays that pass wide_tame use these reciprocals, and their direction components are normal
+                    // numbers between 2^-40 and 2^40: the short form returns the division's bits for them.
+                    inv = ray_inverse_quick(d);
                     h = miss_rec();
                     ray = i;
                     if (wide_tame(S, o, d)) { w.cur = 0u; w.sp = 0u; w.best_slot = 0u; }
