@@ -58,6 +58,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     DevBuf q[6], hits, rad, counter;
     DevBuf pre_hits, pre_work;               // large scenes: k_extend_wide's per-ray hits and its grab counter
+    DevBuf jitter;                           // the batch's per-sample jitters (k_jitter)
     // Per-bounce counters travel to the host through a ring: the device slot of bounce d is
     // d % kRing; the next bounce's extend launch stores it into the pinned mirror
     // {tag << 32 | vertices, tag << 32 | rays}.
@@ -657,7 +658,7 @@ int orion_hip_scene_destroy(OrionScene* s) {
     s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release(); s->s_work.release(); s->s_lights.release();
     for (Lane& L : s->lane) {
         for (DevBuf& b : L.q) b.release();
-        L.hits.release(); L.rad.release(); L.counter.release(); L.pre_hits.release(); L.pre_work.release();
+        L.hits.release(); L.rad.release(); L.counter.release(); L.pre_hits.release(); L.pre_work.release(); L.jitter.release();
         if (L.h_count) (void)hipHostFree(L.h_count);
         if (L.resolved) (void)hipEventDestroy(L.resolved);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -811,6 +812,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     const uint64_t P = (uint64_t)F.tile_w * F.tile_h;
     uint64_t per_batch = s->batch_paths / P;
     if (per_batch > (uint64_t)(p->spp_end - p->spp_begin)) per_batch = p->spp_end - p->spp_begin;
+    if (per_batch > (1u << 20)) per_batch = 1u << 20;   // (the jitter table and the camera-ray generator's short divisions)
     if (per_batch < 1) per_batch = 1;
     {
         // The queues of a batch take 144 bytes per path and lane.  Larger batches are faster (fewer thin bounce tails per
@@ -897,6 +899,9 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         B.bound = (uint32_t)(P * ns);
         B.rays_in = B.bound;
         HIP_TRY(hipMemsetAsync(B.count, 0, kRing * 16, L.stream));
+        if (int rc = L.jitter.reserve((size_t)ns * sizeof(float2))) return rc;
+        hipLaunchKernelGGL(k_jitter, dim3(grid_for(ns)), dim3(kBlock), 0, L.stream, B.F, static_cast<float2*>(L.jitter.p));
+        HIP_TRY(hipGetLastError());
         return 0;
     };
     // Launches bounce `depth` of a batch: closest hits, then shading.
@@ -912,7 +917,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         auto extend = [&](auto kernel) {
             launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((B.bound + tile - 1) / tile), dim3(kBlock), s->view, B.F, B.rad, B.qa,
                       prev, B.bound, B.qb, B.hits, cnt, clear, B.L->h_count + 2 * prev_slot, B.tags[prev_slot], n_bins,
-                      static_cast<const float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p));
+                      static_cast<const float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p), static_cast<const float2*>(B.L->jitter.p));
         };
         if (draw_rays && depth > 0) {
             uint32_t grab, grid;
