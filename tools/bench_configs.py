@@ -30,7 +30,8 @@ def main():
         if forced:
             sc.set_option("traversal", forced)
         acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-        sc.render(fr.camera12, W, H, 0, min(4, spp), ls, fr.rtc.recursion_level, seed=1, lights=fr.rtc.lights, accum=acc)
+        # (untimed, with the same sample count: the queues are sized for the call's samples per batch)
+        sc.render(fr.camera12, W, H, 0, spp, ls, fr.rtc.recursion_level, seed=1, lights=fr.rtc.lights, accum=acc)
         sc.profile(True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
