@@ -947,6 +947,8 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         with_mode(mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
             auto shade = point ? k_shade<MODE, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf : k_shade<MODE, false>);
+            // (the first vertices of a large scene left to choose: their shadow rays walk together, see the kernel)
+            if (MODE == MODE_WIDE && point && depth == 0 && s->traversal == 0 && s->wave_ok) shade = k_shade_wide_point0;
             launch_on(s, B.L->stream, ORION_KERNEL_SHADE, 0, shade, dim3(grid_for(B.bound)), dim3(kBlock), s->view, B.F, depth, B.qb, cnt, B.hits, B.qa, cnt + 1, B.rad);
         });
         HIP_TRY(hipGetLastError());

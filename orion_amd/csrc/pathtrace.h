@@ -723,7 +723,8 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
 // (orion/raytracer.cpp:116-206).  POINT selects the point-light branch.  Adds the vertex's light
 // to rad[pid] (lanes with `writer` set do the store) and returns whether the path goes on, with
 // the next ray's origin (the biased hit point), direction and throughput.
-template <int MODE, bool POINT>
+// SHADOW: the walk of the point lights' shadow rays (MODE unless the caller knows better).
+template <int MODE, bool POINT, int SHADOW = MODE>
 __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams& F, uint32_t depth, bool live, bool writer,
                                            V3 o, V3 d, V3 T, uint32_t pid, uint32_t pixel, uint32_t sample, const HitRec& h,
                                            float4* __restrict__ rad, V3& biased, V3& next_d, V3& next_T) {
@@ -831,7 +832,7 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
             V3 sd = splat(1.0f);
             if (live) sd = lpos - hitPos;
             HitRec h2 = miss_rec();
-            traverse<MODE, true>(S, biased, sd, h2, live);
+            traverse<SHADOW, true>(S, biased, sd, h2, live);
             if (live && h2.gtri == kInvalid)
                 color = color + color_phong(ka, kd, ks, shininess, d, normal, hitPos, lpos, ld3(F.lights[li].color), F.lights[li].intensity);
         }
@@ -854,7 +855,7 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
 
 // Input: the `*n_live` vertex records k_extend left (every one of them a hit); the grid is sized
 // for the ray count, blocks past the live count leave at once.
-template <int MODE, bool POINT>
+template <int MODE, bool POINT, int SHADOW = MODE>
 __device__ __forceinline__ void shade_block(const SceneView& S, const FrameParams& F, uint32_t depth, Queues qin,
                                             const unsigned long long* __restrict__ n_live, const HitRec* __restrict__ hits,
                                             Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad) {
@@ -873,7 +874,7 @@ __device__ __forceinline__ void shade_block(const SceneView& S, const FrameParam
         h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
     }
     V3 biased, next_d, next_T;
-    const bool cont = shade_core<MODE, POINT>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
+    const bool cont = shade_core<MODE, POINT, SHADOW>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
     const uint32_t slot = queue_slot(cont, false, out_count);
     if (cont) {
         qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
@@ -888,6 +889,18 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
                                                   const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
                                                   float4* __restrict__ rad) {
     shade_block<MODE, POINT>(S, F, depth, qin, n_live, hits, qout, out_count, rad);
+}
+
+// The first vertices of a point-light frame on a large scene: a wave holds samples of one pixel (path_pixel), points a
+// fraction of a pixel apart that all look at the same light, and the wave-synchronous walk of such shadow rays costs
+// little more than one ray's (nanosuit frame: this launch 1.63 -> 1.10 ms per 64 spp against the per-lane wide walk).
+#ifndef ORION_SHADOW0_MODE
+#define ORION_SHADOW0_MODE MODE_WAVE
+#endif
+__global__ __launch_bounds__(kBlock) void k_shade_wide_point0(SceneView S, FrameParams F, uint32_t depth, Queues qin, const unsigned long long* __restrict__ n_live,
+                                                              const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
+                                                              float4* __restrict__ rad) {
+    shade_block<MODE_WIDE, true, ORION_SHADOW0_MODE>(S, F, depth, qin, n_live, hits, qout, out_count, rad);
 }
 
 // The wave-synchronous BRDF form, the kernel a Cornell-class frame spends two thirds of its time
