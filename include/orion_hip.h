@@ -199,8 +199,8 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *                 than this left (default 32 Mi; 0 = one batch at a time, half the memory)
  *   "draw_rays"   1 (default): on scenes that walk the 4-wide tree, the closest hits of bounce rays are found
  *                 by waves that draw rays from the queue as their lanes finish; 0: four rays per thread
- *   "wave_ahead"  1 (default): the wave-synchronous walk of a large scene's camera rays asks for the next node
- *                 and the next triangle of a leaf while it tests the present one; 0: it fetches each when it gets there
+ *   "wave_ahead"  1: the wave-synchronous walk of a large scene's camera rays asks for the next node and the next
+ *                 triangle of a leaf while it tests the present one; 0 (default): it fetches each when it gets there
  *   "queue_budget_mib" memory a render call's queues may take, in MiB (0, the default: three quarters of
  *                 the device's free memory); the call halves its samples per batch until they fit
  *   "fail_at_bounce" test hook: the n-th bounce a render call launches from now on fails (once) with

@@ -119,7 +119,7 @@ struct OrionScene {
     uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
     uint64_t queue_budget = 0;            // bytes the render queues may take (0: three quarters of the device's free memory)
     bool draw_rays = true;                // large scenes: bounce rays are handed to lanes as they finish (k_extend_wide)
-    bool wave_ahead = true;               // large scenes: the primary rays' wave-synchronous walk fetches one record ahead
+    bool wave_ahead = false;              // large scenes: the primary rays' wave-synchronous walk fetches one record ahead (slower since a wave holds one pixel's samples)
     // staging + queues
     DevBuf s_org, s_dir, s_out, s_accum;
     DevBuf s_work;                    // grab counter + chunk list of the large-scene ray queries

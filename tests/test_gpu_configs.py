@@ -131,7 +131,7 @@ def test_big_scene_walk_choice_changes_nothing():
     sc.set_option("draw_rays", 0)          # bounce rays four per thread instead of handed to lanes as they finish
     imgs.append(sc.render(cam, W, H, 0, 4, 1, 3, seed=4, lights=fr.rtc.lights).copy())
     sc.set_option("draw_rays", 1)
-    sc.set_option("wave_ahead", 0)         # camera rays without the look-ahead for the next node and triangle
+    sc.set_option("wave_ahead", 1)         # camera rays with the look-ahead for the next node and triangle
     imgs.append(sc.render(cam, W, H, 0, 4, 1, 3, seed=4, lights=fr.rtc.lights).copy())
     sc.close()
     assert imgs[0][:, :, :3].max() > 0

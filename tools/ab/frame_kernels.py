@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event time of one pass of a configured frame, one batch at a time (no two-lane overlap), for A/B
-builds (ORION_HIP_LIB).  Usage: frame_kernels.py [config ...]   SPP=64, BVH=median|middle|sah (environment)"""
+builds (ORION_HIP_LIB).  Usage: frame_kernels.py [config ...]   SPP=64, BVH=median|middle|sah, TRAVERSAL=<option> (environment)"""
 import os
 import sys
 
@@ -19,6 +19,8 @@ for name in sys.argv[1:] or ["c3_nanosuit_fhd", "c3b_nanosuit_bounce_fhd"]:
     W, H = fr.rtc.xres, fr.rtc.yres
     sc = api.Scene(fr.model, device=0)
     sc.set_option("overlap_below", 0)
+    if os.environ.get("TRAVERSAL"):
+        sc.set_option("traversal", int(os.environ["TRAVERSAL"]))
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     args = dict(seed=1, lights=fr.rtc.lights, accum=acc)
     sc.render(fr.camera12, W, H, 0, spp, ls, fr.rtc.recursion_level, **args)
