@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kBlock) ORION_DRAW_ATTR void k_extend_wide(SceneVie
 
 // GEN: the first bounce.  The rays are the primary rays, computed here from the path index
 // instead of being read from a queue (no generate pass, no 64 B/path round trip through HBM), and
-// every path's radiance slot is zeroed.
+// the radiance slot of every path that misses is zeroed (the others get theirs written by their first vertex's shade launch).
 template <int MODE, uint32_t kRaysPerThread, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, float4* __restrict__ rad,
                                                    Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
@@ -714,7 +714,9 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
             qout.T[dst] = c;
             reinterpret_cast<float4*>(hits)[dst] = h;
         }
-        if (GEN && tile0 + slot < n) rad[tile0 + slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // a path that misses contributes nothing (its slot must read zero in k_resolve); one that hits gets its slot
+        // written by the shade launch of its first vertex
+        if (GEN && tile0 + slot < n && gtri == kInvalid) rad[tile0 + slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     housekeeping();
 }
@@ -790,8 +792,9 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
                 unsafeAtomicAdd(rp, acc.x); unsafeAtomicAdd(rp + 1, acc.y); unsafeAtomicAdd(rp + 2, acc.z);
             }
 #else
-            if (writer) {
-                const float4 r0 = rad[pid];
+            if (writer) {   // (a path's first vertex finds no sum yet: k_extend zeroes the slots of the paths that miss only)
+                float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (depth != 0) r0 = rad[pid];
                 const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
                 rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
             }
@@ -838,7 +841,8 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
         }
         if (live) {
             if (writer) {
-                const float4 r0 = rad[pid];
+                float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (depth != 0) r0 = rad[pid];
                 const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
                 rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
             }
