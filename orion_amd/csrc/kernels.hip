@@ -59,6 +59,7 @@ struct Lane {
     DevBuf q[6], hits, rad, counter;
     DevBuf pre_hits, pre_work;               // large scenes: k_extend_wide's per-ray hits and its grab counter
     DevBuf jitter;                           // the batch's per-sample jitters (k_jitter)
+    DevBuf hit_mask;                         // a bit per path: did its camera ray hit anything (k_extend's first launch, k_resolve)
     // Per-bounce counters travel to the host through a ring: the device slot of bounce d is
     // d % kRing; the next bounce's extend launch stores it into the pinned mirror
     // {tag << 32 | vertices, tag << 32 | rays}.
@@ -658,7 +659,7 @@ int orion_hip_scene_destroy(OrionScene* s) {
     s->s_org.release(); s->s_dir.release(); s->s_out.release(); s->s_accum.release(); s->s_work.release(); s->s_lights.release();
     for (Lane& L : s->lane) {
         for (DevBuf& b : L.q) b.release();
-        L.hits.release(); L.rad.release(); L.counter.release(); L.pre_hits.release(); L.pre_work.release(); L.jitter.release();
+        L.hits.release(); L.rad.release(); L.counter.release(); L.pre_hits.release(); L.pre_work.release(); L.jitter.release(); L.hit_mask.release();
         if (L.h_count) (void)hipHostFree(L.h_count);
         if (L.resolved) (void)hipEventDestroy(L.resolved);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -899,6 +900,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         B.bound = (uint32_t)(P * ns);
         B.rays_in = B.bound;
         HIP_TRY(hipMemsetAsync(B.count, 0, kRing * 16, L.stream));
+        if (int rc = L.hit_mask.reserve((max_paths + 63) / 64 * 8)) return rc;
         if (int rc = L.jitter.reserve((size_t)ns * sizeof(float2))) return rc;
         hipLaunchKernelGGL(k_jitter, dim3(grid_for(ns)), dim3(kBlock), 0, L.stream, B.F, static_cast<float2*>(L.jitter.p));
         HIP_TRY(hipGetLastError());
@@ -917,7 +919,8 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         auto extend = [&](auto kernel) {
             launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((B.bound + tile - 1) / tile), dim3(kBlock), s->view, B.F, B.rad, B.qa,
                       prev, B.bound, B.qb, B.hits, cnt, clear, B.L->h_count + 2 * prev_slot, B.tags[prev_slot], n_bins,
-                      static_cast<const float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p), static_cast<const float2*>(B.L->jitter.p));
+                      static_cast<const float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p), static_cast<const float2*>(B.L->jitter.p),
+                      static_cast<unsigned long long*>(B.L->hit_mask.p));
         };
         if (draw_rays && depth > 0) {
             uint32_t grab, grid;
@@ -1012,7 +1015,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             }
             // The accumulator takes the batches' sums in ascending sample order, whichever lane they ran on.
             if (last_resolve && last_resolve != cur.L) HIP_TRY(hipStreamWaitEvent(cur.L->stream, last_resolve->resolved, 0));
-            launch_on(s, cur.L->stream, ORION_KERNEL_RESOLVE, P, k_resolve, dim3(grid_for(P)), dim3(kBlock), cur.F, cur.rad, d_accum);
+            launch_on(s, cur.L->stream, ORION_KERNEL_RESOLVE, P, k_resolve, dim3(grid_for(P)), dim3(kBlock), cur.F, cur.rad, d_accum, static_cast<const uint32_t*>(cur.L->hit_mask.p));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(cur.L->resolved, cur.L->stream));
             last_resolve = cur.L;

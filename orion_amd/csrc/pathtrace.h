@@ -633,13 +633,15 @@ __global__ __launch_bounds__(kBlock) ORION_DRAW_ATTR void k_extend_wide(SceneVie
 
 // GEN: the first bounce.  The rays are the primary rays, computed here from the path index
 // instead of being read from a queue (no generate pass, no 64 B/path round trip through HBM), and
-// the radiance slot of every path that misses is zeroed (the others get theirs written by their first vertex's shade launch).
+// a bit per path says whether it hit anything: a path that misses contributes nothing and its radiance slot is never
+// touched, one that hits gets its slot written by its first vertex's shade launch.
 template <int MODE, uint32_t kRaysPerThread, bool GEN>
 __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, float4* __restrict__ rad,
                                                    Queues qin, const unsigned long long* __restrict__ prev, uint32_t n_bound,
                                                    Queues qout, HitRec* __restrict__ hits, unsigned long long* __restrict__ counter,
                                                    unsigned long long* __restrict__ clear, unsigned long long* publish, uint32_t tag, uint32_t n_bins,
-                                                   const float4* __restrict__ pre_hits, uint32_t* __restrict__ pre_work, const float2* __restrict__ jitter) {
+                                                   const float4* __restrict__ pre_hits, uint32_t* __restrict__ pre_work, const float2* __restrict__ jitter,
+                                                   unsigned long long* __restrict__ hit_mask) {
     constexpr uint32_t kTile = kBlock * kRaysPerThread;   // rays per block
     __shared__ float4 s_hit[kTile];
     __shared__ uint16_t s_rank[kTile];
@@ -680,6 +682,10 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
             traverse<MODE, false>(S, o, d, h, active);
         }
         s_hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.gtri));
+        if (GEN) {   // which of the wave's 64 paths hit something: all k_resolve needs to know about the others
+            const unsigned long long m = __ballot(h.gtri != kInvalid);
+            if (lane_id() == 0u && i < n) hit_mask[i >> 6] = m;   // (lane 0 holds the wave's first path)
+        }
         if (h.gtri != kInvalid) {
             const uint32_t bin = min(h.gtri, n_bins - 1u);
             s_rank[slot] = (uint16_t)atomicAdd(&s_cnt[bin], 1u);
@@ -714,9 +720,6 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
             qout.T[dst] = c;
             reinterpret_cast<float4*>(hits)[dst] = h;
         }
-        // a path that misses contributes nothing (its slot must read zero in k_resolve); one that hits gets its slot
-        // written by the shade launch of its first vertex
-        if (GEN && tile0 + slot < n && gtri == kInvalid) rad[tile0 + slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     housekeeping();
 }
@@ -792,7 +795,7 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
                 unsafeAtomicAdd(rp, acc.x); unsafeAtomicAdd(rp + 1, acc.y); unsafeAtomicAdd(rp + 2, acc.z);
             }
 #else
-            if (writer) {   // (a path's first vertex finds no sum yet: k_extend zeroes the slots of the paths that miss only)
+            if (writer) {   // (a path's first vertex finds no sum yet; nobody reads the slots of the paths that miss)
                 float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (depth != 0) r0 = rad[pid];
                 const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
@@ -947,26 +950,35 @@ __global__ __launch_bounds__(kBlock) void k_tail(SceneView S, FrameParams F, uin
 }
 
 // image[i][j] += tracedColor for the batch's samples in ascending order (orion/raytracer.cpp:84).  A pixel's samples
-// lie side by side (path_pixel): a thread reads them a cache line (eight samples) at a time, so that every line
-// is fetched once.
-__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams F, const float4* __restrict__ rad, float4* __restrict__ accum) {
+// lie side by side (path_pixel); the slots of paths that missed everything (hit_mask: a bit per path, k_extend's
+// first launch) hold nothing and count as the zero they stand for, which leaves a sum as it is.
+__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams F, const float4* __restrict__ rad, float4* __restrict__ accum,
+                                                    const uint32_t* __restrict__ hit_mask) {
     const uint32_t P = F.tile_w * F.tile_h;
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= P) return;
     const uint32_t py = F.tile_y0 + p / F.tile_w, px = F.tile_x0 + p % F.tile_w;
     float4 acc = accum[(size_t)py * F.width + px];
-    const float4* mine = rad + (size_t)p * F.n_samples;
+    const size_t first = (size_t)p * F.n_samples;
     uint32_t k = 0;
-    for (; k + 8 <= F.n_samples; k += 8) {
+    for (; k + 8 <= F.n_samples; k += 8) {   // eight samples at a time: their loads are under way together
+        const size_t i = first + k;
+        const uint32_t sh = (uint32_t)(i & 31u);
+        const uint32_t w0 = hit_mask[i >> 5], w1 = sh > 24u ? hit_mask[(i >> 5) + 1] : 0u;
+        const uint32_t bits = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> sh) & 0xFFu;
         float4 c[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) c[i] = mine[k + i];
+        for (int j = 0; j < 8; j++) { c[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); if (bits >> j & 1u) c[j] = rad[i + j]; }
 #pragma unroll
-        for (int i = 0; i < 8; i++) { acc.x += c[i].x; acc.y += c[i].y; acc.z += c[i].z; acc.w += 1.0f; }
+        for (int j = 0; j < 8; j++) { acc.x += c[j].x; acc.y += c[j].y; acc.z += c[j].z; acc.w += 1.0f; }
     }
     for (; k < F.n_samples; k++) {
-        const float4 c = mine[k];
-        acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
+        const size_t i = first + k;
+        if (hit_mask[i >> 5] >> (i & 31u) & 1u) {
+            const float4 c = rad[i];
+            acc.x += c.x; acc.y += c.y; acc.z += c.z;
+        }
+        acc.w += 1.0f;
     }
     accum[(size_t)py * F.width + px] = acc;
 }

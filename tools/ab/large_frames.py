@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Frames of several path batches: what batch size (option batch_paths) and the threshold of the two-lane overlap
 (overlap_below) are worth.  Every setting renders once untimed (the queues are reallocated when the batch size
-changes) and then twice timed.  Usage: large_frames.py [config ...]   SPP=512 (environment)"""
+changes) and then twice timed.  Usage: large_frames.py [config ...]   SPP=512, SETTINGS="256:32,512:32" (environment)"""
 import os
 import sys
 import time
@@ -13,6 +13,8 @@ sys.path.insert(0, ROOT)
 from orion_amd import api  # noqa: E402
 
 SETTINGS = [(64 << 20, 4 << 20), (128 << 20, 8 << 20), (128 << 20, 16 << 20), (256 << 20, 16 << 20), (256 << 20, 32 << 20), (256 << 20, 64 << 20)]
+if os.environ.get("SETTINGS"):      # "batch Mi:overlap Mi,..."
+    SETTINGS = [tuple(int(v) << 20 for v in x.split(":")) for x in os.environ["SETTINGS"].split(",")]
 spps = [int(x) for x in os.environ.get("SPP", "512").split(",")]
 for name in sys.argv[1:] or ["c3_nanosuit_fhd", "c3b_nanosuit_bounce_fhd"]:
     ls = 2 if "cornell" in name else 1
