@@ -244,24 +244,43 @@ __device__ __forceinline__ void traverse_lane(const SceneView& S, V3 o, V3 d, Hi
 // ---------------------------------------------------------------------------
 template <bool QUICK_DIV, bool AHEAD>
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast);
+// Large scenes: one test of the box around all the meshes' roots (the spare record behind the node array) before the
+// roots are tested one after the other.  Exact: for rays without NaN products (`fast`, wave-uniform) the slab test is
+// monotone in the box, so a ray that misses this box fails the reference's test at every root.  Camera rays that miss
+// a model of a dozen meshes are done after one box test instead of a dozen.  Smaller scenes are walked from inside
+// (nothing to skip), and there every instruction counts.
+constexpr uint32_t kSceneBoxAbove = 384;   // nodes
+__device__ __forceinline__ void scene_box_gate(const SceneView& S, V3 o, V3 inv, bool fast, bool& active, uint32_t& next) {
+    if (S.n_nodes > kSceneBoxAbove && fast) {
+        const Node* all = S.nodes + S.n_nodes;
+        const bool in = active && slab_hit_fast(all->lo[0], all->lo[1], all->lo[2], all->hi[0], all->hi[1], all->hi[2], o, inv);
+        if (!in) next = kInvalid;
+        active = in;
+    }
+}
 // Closest hit only.  A point-light shadow query ("is anything hit at t >= 0") is answered by the
 // same walk: a triangle is accepted against t = +inf under exactly the any-hit condition, and later
 // acceptances never undo a hit, so "h.gtri is set" means the same in both.  (A separate any-hit
 // loop that stopped at the first acceptance was 30 % slower than this walk run to its end.)
-__device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
+template <bool GATE>
+__device__ __forceinline__ void traverse_wave_from(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) {
     bool d_small, d_normal;
     dir_class(d, S.dir_bound, d_small, d_normal);
     const bool quick_det = __all(!active || d_small), quick_inv = __all(!active || d_normal);   // wave-uniform
     const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
     // wave-uniform choice of the slab arithmetic; reciprocals of normal numbers below 2^126 are finite and not zero
     const bool fast = quick_inv ? __all(!active || finite3(o)) : __all(!active || slab_safe(o, inv));
-    const uint32_t next = active ? 0u : kInvalid;
+    uint32_t next = active ? 0u : kInvalid;
     const uint32_t ufast = __builtin_amdgcn_readfirstlane(fast ? 1u : 0u);
+    if (GATE) scene_box_gate(S, o, inv, fast, active, next);
     if (S.n_nodes && __any(active)) {   // (the walk relies on a lane being there to follow)
         if (quick_det) traverse_wave_closest_asm<true, false>(S, o, d, inv, h, next, ufast);
         else traverse_wave_closest_asm<false, false>(S, o, d, inv, h, next, ufast);
     }
 }
+__device__ __forceinline__ void traverse_wave(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) { traverse_wave_from<false>(S, o, d, h, active); }
+// ... for rays that may come from outside a large scene (camera rays, coherent ray queries): the scene's box first.
+__device__ __forceinline__ void traverse_wave_outside(const SceneView& S, V3 o, V3 d, HitRec& h, bool active) { traverse_wave_from<true>(S, o, d, h, active); }
 
 // The same walk for trees of thousands of nodes, whose records come from the L2 (the scalar cache holds a few hundred):
 // there the loop waits for its scalar loads more than it computes (camera rays on a 13 k-node model: the waves of the
@@ -273,8 +292,9 @@ __device__ __forceinline__ void traverse_wave_ahead(const SceneView& S, V3 o, V3
     const bool quick_det = __all(!active || d_small), quick_inv = __all(!active || d_normal);   // wave-uniform
     const V3 inv = quick_inv ? ray_inverse_quick(d) : ray_inverse(d);
     const bool fast = quick_inv ? __all(!active || finite3(o)) : __all(!active || slab_safe(o, inv));
-    const uint32_t next = active ? 0u : kInvalid;
+    uint32_t next = active ? 0u : kInvalid;
     const uint32_t ufast = __builtin_amdgcn_readfirstlane(fast ? 1u : 0u);
+    scene_box_gate(S, o, inv, fast, active, next);
     if (S.n_nodes && __any(active)) {
         if (quick_det) traverse_wave_closest_asm<true, true>(S, o, d, inv, h, next, ufast);
         else traverse_wave_closest_asm<false, true>(S, o, d, inv, h, next, ufast);

@@ -598,7 +598,16 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     v.n_nodes = (uint32_t)nodes.size(); v.n_tris = (uint32_t)tris.size();
     // One spare record behind each array: the walk that asks for the next node ahead of time (traverse_wave_ahead)
     // reads one past the node it is at.
-    nodes.push_back(Node{}); tris.push_back(Tri{});
+    // The spare node record holds the box around all the meshes' roots (traverse_wave tests it first on large scenes).
+    {
+        Node all{};
+        for (int a = 0; a < 3; a++) { all.lo[a] = INFINITY; all.hi[a] = -INFINITY; }
+        for (const std::vector<uint32_t>& w : node_where)
+            if (!w.empty() && w[0] != kInvalid)
+                for (int a = 0; a < 3; a++) { all.lo[a] = std::fmin(all.lo[a], nodes[w[0]].lo[a]); all.hi[a] = std::fmax(all.hi[a], nodes[w[0]].hi[a]); }
+        nodes.push_back(all);
+    }
+    tris.push_back(Tri{});
     if ((rc = upload(s, nodes, &v.nodes))) return bail(rc);
     if ((rc = upload(s, tris, &v.tris))) return bail(rc);
     nodes.pop_back(); tris.pop_back();
@@ -929,16 +938,18 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                       static_cast<float4*>(B.L->pre_hits.p), grab, static_cast<uint32_t*>(B.L->pre_work.p));
             if (wide) extend(k_extend<MODE_PRE, kRaysWide, false>); else extend(k_extend<MODE_PRE, 1, false>);
         } else {
-            // Rays of neighbouring pixels keep a wave together whatever the size of the tree, and the
+            // The samples of one pixel keep a wave together whatever the size of the tree, and the
             // wave-synchronous walk costs the union of its lanes' paths: the primary rays take it in
-            // scenes of any size.  (The shadow rays a point-light frame casts from their hit points do
-            // not: measured on the 38 k-node nanosuit frame, the per-lane walk is 25 % faster on those.)
+            // scenes of any size (and so do the shadow rays a point-light frame casts from their hit
+            // points, k_shade_wide_point0; the rays of later bounces do not).
             const bool coherent = depth == 0 && per_lane && s->traversal == 0 && s->wave_ok;
             if (coherent && s->wave_ahead) {
                 // ... in its form that fetches the next record while it tests the present one: in a tree of thousands of
                 // nodes the walk waits for its scalar loads (they come from the L2), not for the vector ALU.
                 if (wide) extend(k_extend<MODE_WAVE_AHEAD, kRaysWide, true>); else extend(k_extend<MODE_WAVE_AHEAD, 1, true>);
-            } else with_mode(coherent ? (int)MODE_WAVE : mode, [&](auto M) {
+            } else if (coherent) {   // ... with the scene's box ahead of the roots (most camera rays of such a frame miss the model)
+                if (wide) extend(k_extend<MODE_WAVE_OUTSIDE, kRaysWide, true>); else extend(k_extend<MODE_WAVE_OUTSIDE, 1, true>);
+            } else with_mode(mode, [&](auto M) {
                 constexpr int MODE = decltype(M)::value;
                 if (depth == 0) {   // primary rays are generated inside the launch
                     if (wide) extend(k_extend<MODE, kRaysWide, true>); else extend(k_extend<MODE, 1, true>);

@@ -39,7 +39,8 @@ static_assert(kBlock == kWideBlock, "the wide walk's stack is laid out for this 
 #define ORION_EXPERIMENT_NO_RAD 0
 #endif
 // MODE_WAVE_AHEAD: MODE_WAVE through the walk that fetches one record ahead (traverse_wave_ahead; trees of thousands of nodes).
-enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4, MODE_WIDE = 5, MODE_ADAPT_WIDE = 6, MODE_PRE = 7, MODE_WAVE_AHEAD = 8 };
+// MODE_WAVE_OUTSIDE: MODE_WAVE for rays that may come from outside a large scene: the scene's box is tested first (traverse_wave_outside).
+enum { MODE_LANE = 0, MODE_WAVE = 1, MODE_EACH = 2, MODE_SAME = 3, MODE_ADAPT = 4, MODE_WIDE = 5, MODE_ADAPT_WIDE = 6, MODE_PRE = 7, MODE_WAVE_AHEAD = 8, MODE_WAVE_OUTSIDE = 9 };
 
 // True for every lane of a wave whose active rays share their origin exactly and lie within about
 // 25 degrees of the first active ray's direction.
@@ -60,11 +61,13 @@ __device__ __forceinline__ void traverse(const SceneView& S, V3 o, V3 d, HitRec&
         traverse_wave(S, o, d, h, active);   // (answers any-hit queries too, see there)
     } else if (MODE == MODE_WAVE_AHEAD) {
         traverse_wave_ahead(S, o, d, h, active);
+    } else if (MODE == MODE_WAVE_OUTSIDE) {
+        traverse_wave_outside(S, o, d, h, active);
     } else if (MODE == MODE_ADAPT) {
-        if (wave_is_coherent(o, d, active)) traverse_wave(S, o, d, h, active);
+        if (wave_is_coherent(o, d, active)) traverse_wave_outside(S, o, d, h, active);
         else if (active) traverse_lane<ANY>(S, o, d, h);
     } else if (MODE == MODE_ADAPT_WIDE) {
-        if (wave_is_coherent(o, d, active)) traverse_wave(S, o, d, h, active);
+        if (wave_is_coherent(o, d, active)) traverse_wave_outside(S, o, d, h, active);
         else if (active) traverse_wide<ANY>(S, o, d, h);
     } else if (MODE == MODE_WIDE) {
         if (active) traverse_wide<ANY>(S, o, d, h);
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_query_coherent(SceneView S, const fl
         if (active) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); }
         if (wave_is_coherent(o, d, active)) {
             HitRec h = miss_rec();
-            traverse_wave(S, o, d, h, active);
+            traverse_wave_outside(S, o, d, h, active);
             if (active) query_store<ANY>(S, i, h, out, occ);
         } else if (lane == 0) {
             s_left[atomicAdd(&s_nleft, 1u)] = chunk;
