@@ -109,6 +109,13 @@ struct Mesh {
     uint32_t tex[4];       // ambient, diffuse, specular, emissive -> textures[]
     float shininess;
     float area;            // sum of |dot(e1,e2)|/2 over triangles (orion/mesh.hpp:197-208, orion/geometry.hpp:155-157)
+    // Emissive meshes whose vertex normals are all one vector: its unit form, and flat = 1.  A light sample's term
+    // carries the factor max(dot(n, l) * dot(light normal, -l), 0) (orion/material.hpp:95-105); with the light's
+    // normal known before the sample's ray is traced, the samples for which that factor is surely zero are not traced
+    // (shade_core).  flat stays 0 when a sum of zeros could still be NaN: a light intensity or a colour texel that is
+    // not finite.
+    float flat_n[3];
+    uint32_t flat;
 };
 
 // Everything a kernel needs, passed by value.
@@ -157,6 +164,19 @@ struct FrameParams {
     uint32_t seed_lo, seed_hi;
     uint32_t n_lights;
     const Light* lights;       // device memory, n_lights entries (any number: orion/raytracer.cpp:196 loops over a vector)
+    // The batch's queues come in 2^part_log2 partitions of part_stride records each, every one with counters of its
+    // own: block b of a bounce launch serves partition b mod 2^part_log2 (kPartWords below).
+    uint32_t part_log2, part_stride;
 };
+
+// Queue partitions.  A block appends to a queue through one returning 64-bit atomic on the queue's counter, and
+// atomics on ONE address are served one after the other, 11.4 ns each on this chip whatever else the kernels do
+// (tools/micro/atomic_rate.hip): 1.2 million blocks of the shade kernel per 128-spp Cornell pass cannot finish in
+// less than 13 ms through one counter.  Sixteen counters 128 bytes apart take 0.5 ns per append.  A partition is a
+// closed chain: the block that reads partition k appends to partition k of the next queue, so a partition's
+// count never grows from bounce to bounce and its region of part_stride records, sized for the first bounce, holds.
+constexpr uint32_t kPartsLog2 = 4, kParts = 1u << kPartsLog2;
+constexpr uint32_t kPartWords = 16;                     // 64-bit words between two partitions' counters (128 bytes)
+constexpr uint32_t kSlotWords = kParts * kPartWords;    // ... and between two bounces' counter slots
 
 } // namespace orion_dev

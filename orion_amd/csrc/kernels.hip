@@ -62,8 +62,8 @@ struct Lane {
     DevBuf hit_mask;                         // a bit per path: did its camera ray hit anything (k_extend's first launch, k_resolve)
     // Per-bounce counters travel to the host through a ring: the device slot of bounce d is
     // d % kRing; the next bounce's extend launch stores it into the pinned mirror
-    // {tag << 32 | vertices, tag << 32 | rays}.
-    unsigned long long* h_count = nullptr;   // pinned and coherent, kRing x 2 words
+    // {tag << 32 | vertices, tag << 32 | rays, tag << 32 | rays of the largest queue partition, unused}.
+    unsigned long long* h_count = nullptr;   // pinned and coherent, kRing x 4 words
     hipEvent_t resolved = nullptr;           // after the lane's newest k_resolve
 };
 
@@ -266,15 +266,15 @@ struct Flattener {
     }
 };
 
-// Waits until the device has stored both counters of a bounce under `tag` into their pinned slot.
+// Waits until the device has stored the three counters of a bounce under `tag` into their pinned slot.
 // The wait is a poll of host memory; it gives up when the stream has drained (or failed) without
 // the tag turning up.
-int await_counters(hipStream_t stream, const unsigned long long* slot, uint32_t tag, uint32_t out[2]) {
+int await_counters(hipStream_t stream, const unsigned long long* slot, uint32_t tag, uint32_t out[3]) {
     const volatile unsigned long long* v = slot;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spin = 0;; spin++) {
-        const unsigned long long a = v[0], b = v[1];
-        if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag) { out[0] = (uint32_t)a; out[1] = (uint32_t)b; return 0; }
+        const unsigned long long a = v[0], b = v[1], c = v[2];
+        if ((uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag && (uint32_t)(c >> 32) == tag) { out[0] = (uint32_t)a; out[1] = (uint32_t)b; out[2] = (uint32_t)c; return 0; }
         for (int k = 0; k < 32; k++) __builtin_ia32_pause();   // poll gently: the device's store has to win the line
         if ((spin & 0x3FF) == 0x3FF) {
             const hipError_t q = hipStreamQuery(stream);
@@ -283,8 +283,8 @@ int await_counters(hipStream_t stream, const unsigned long long* slot, uint32_t 
                 continue;
             }
             if (q != hipSuccess) return fail(2, std::string("bounce loop: ") + hipGetErrorString(q));
-            const unsigned long long a2 = v[0], b2 = v[1];   // the stream is idle: every store has landed
-            if ((uint32_t)(a2 >> 32) == tag && (uint32_t)(b2 >> 32) == tag) { out[0] = (uint32_t)a2; out[1] = (uint32_t)b2; return 0; }
+            const unsigned long long a2 = v[0], b2 = v[1], c2 = v[2];   // the stream is idle: every store has landed
+            if ((uint32_t)(a2 >> 32) == tag && (uint32_t)(b2 >> 32) == tag && (uint32_t)(c2 >> 32) == tag) { out[0] = (uint32_t)a2; out[1] = (uint32_t)b2; out[2] = (uint32_t)c2; return 0; }
             return fail(2, "bounce loop: counters were not published");
         }
     }
@@ -515,6 +515,21 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         dm.shininess = md.shininess; dm.area = area;
         const bool is_emissive = md.emissive_color[0] != 0.0f || md.emissive_color[1] != 0.0f || md.emissive_color[2] != 0.0f;
         if (is_emissive && ntri) emissive.push_back(mi);
+        dm.flat = 0; dm.flat_n[0] = dm.flat_n[1] = dm.flat_n[2] = 0.0f;
+        if (is_emissive && ntri) {   // one normal for the whole light, finite intensities: see Mesh::flat
+            const float* n0 = attrs[tri_base].n0;
+            bool flat = true;
+            for (uint32_t o = 0; o < ntri && flat; o++) {
+                const TriAttr& a = attrs[tri_base + o];
+                flat = !std::memcmp(a.n0, n0, 12) && !std::memcmp(a.n1, n0, 12) && !std::memcmp(a.n2, n0, 12) &&
+                       std::isfinite(tris[slot_base + o].light_intensity);
+            }
+            const double len = std::sqrt((double)n0[0] * n0[0] + (double)n0[1] * n0[1] + (double)n0[2] * n0[2]);
+            if (flat && std::isfinite(len) && len > 1e-18) {
+                for (int c = 0; c < 3; c++) dm.flat_n[c] = (float)(n0[c] / len);
+                dm.flat = 1;
+            }
+        }
         tri_base += ntri;
     }
 
@@ -560,6 +575,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     std::vector<Texture> dtex(n_textures);
     std::vector<float> texf;
     std::vector<uint8_t> texb;
+    bool texels_finite = true;   // (bytes always are)
     for (uint32_t t = 0; t < n_textures; t++) {
         const OrionTextureDesc& td = textures[t];
         const size_t px = (size_t)td.width * td.height;
@@ -568,6 +584,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
             dtex[t].offset = (uint32_t)texf.size();
             const float* src = static_cast<const float*>(td.texels);
             texf.insert(texf.end(), src, src + 3 * px);
+            for (size_t i = 0; i < 3 * px && texels_finite; i++) texels_finite = std::isfinite(src[i]);
         } else {
             const size_t bpp = td.format == ORION_TEX_RGB_U8 ? 3 : (td.format == ORION_TEX_RGBA_U8 ? 4 : 1);
             dtex[t].offset = (uint32_t)texb.size();
@@ -575,6 +592,9 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
             texb.insert(texb.end(), src, src + bpp * px);
         }
     }
+
+    if (!texels_finite)
+        for (Mesh& dm : dmeshes) dm.flat = 0;
 
     // ---- upload ----------------------------------------------------------------
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return fail(2, "no HIP device"); }
@@ -588,8 +608,8 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     s->lane[0].stream = s->stream;
     if (hipStreamCreateWithFlags(&s->lane[1].stream, hipStreamNonBlocking) != hipSuccess) { s->lane[1].stream = nullptr; return bail(fail(2, "hipStreamCreate failed")); }
     for (Lane& L : s->lane) {
-        if (hipHostMalloc((void**)&L.h_count, kRing * 16, hipHostMallocCoherent) != hipSuccess) { L.h_count = nullptr; return bail(fail(2, "hipHostMalloc failed")); }
-        std::memset(L.h_count, 0, kRing * 16);
+        if (hipHostMalloc((void**)&L.h_count, kRing * 32, hipHostMallocCoherent) != hipSuccess) { L.h_count = nullptr; return bail(fail(2, "hipHostMalloc failed")); }
+        std::memset(L.h_count, 0, kRing * 32);
         if (hipEventCreateWithFlags(&L.resolved, hipEventDisableTiming) != hipSuccess) { L.resolved = nullptr; return bail(fail(2, "hipEventCreate failed")); }
     }
     if (hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming) != hipSuccess) { s->ev_upload = nullptr; return bail(fail(2, "hipEventCreate failed")); }
@@ -843,7 +863,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         }
     }
     const uint64_t max_paths = P * per_batch;
-    if (max_paths >= 0xFFFFFFFFull) return fail(1, "render: tile has too many pixels for one batch");
+    if (max_paths + kParts * kTileWide >= 0xFFFFFFFFull) return fail(1, "render: tile has too many pixels for one batch");
 
     const size_t img_bytes = (size_t)p->width * p->height * 16;
     const bool accum_dev = is_device_ptr(accum_any);
@@ -879,6 +899,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         float4* rad = nullptr;
         unsigned long long* count = nullptr;
         uint32_t bound = 0;           // >= the number of rays entering the next bounce to launch
+        uint32_t pbound = 0;          // >= the rays of every queue partition entering that bounce (FrameParams::part_log2)
         uint32_t consumed = 0;        // bounces whose counters the host has read
         uint32_t launched = 0;
         uint64_t rays_in = 0;         // rays that entered bounce `consumed`
@@ -886,10 +907,11 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     };
     auto begin = [&](Batch& B, uint64_t index) -> int {
         Lane& L = s->lane[two_lanes ? (index & 1) : 0];
-        for (DevBuf& b : L.q) if (int rc = b.reserve(max_paths * 16)) return rc;
-        if (int rc = L.hits.reserve(max_paths * 16)) return rc;
+        const size_t queue_bytes = (size_t)(max_paths + kParts * kTileWide) * 16;   // (partitions end on tile boundaries)
+        for (DevBuf& b : L.q) if (int rc = b.reserve(queue_bytes)) return rc;
+        if (int rc = L.hits.reserve(queue_bytes)) return rc;
         if (int rc = L.rad.reserve(max_paths * 16)) return rc;
-        if (int rc = L.counter.reserve(kRing * 16)) return rc;
+        if (int rc = L.counter.reserve(kRing * kSlotWords * 8)) return rc;
         if (draw_rays) {
             if (int rc = L.pre_hits.reserve(max_paths * 16)) return rc;
             if (int rc = L.pre_work.reserve(kWorkWords * 4)) return rc;
@@ -908,7 +930,16 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         B.count = static_cast<unsigned long long*>(L.counter.p);
         B.bound = (uint32_t)(P * ns);
         B.rays_in = B.bound;
-        HIP_TRY(hipMemsetAsync(B.count, 0, kRing * 16, L.stream));
+        {   // Queue partitions (device_types.h).  The first bounce's block b leaves its hits in partition b mod parts, so
+            // a partition holds at most ceil(blocks / parts) tiles.  The ray-drawing kernels of large scenes index their
+            // queue as one array and keep one partition.
+            const uint32_t tile0 = B.bound >= kNarrowBelow ? kTileWide : kBlock;   // (bounce() picks the tile the same way)
+            const uint32_t blocks0 = (B.bound + tile0 - 1) / tile0;
+            B.F.part_log2 = draw_rays ? 0u : kPartsLog2;
+            B.F.part_stride = ((blocks0 + (1u << B.F.part_log2) - 1) >> B.F.part_log2) * tile0;
+            B.pbound = B.F.part_stride;
+        }
+        HIP_TRY(hipMemsetAsync(B.count, 0, kRing * kSlotWords * 8, L.stream));
         if (int rc = L.hit_mask.reserve((max_paths + 63) / 64 * 8)) return rc;
         if (int rc = L.jitter.reserve((size_t)ns * sizeof(float2))) return rc;
         hipLaunchKernelGGL(k_jitter, dim3(grid_for(ns)), dim3(kBlock), 0, L.stream, B.F, static_cast<float2*>(L.jitter.p));
@@ -919,15 +950,18 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     auto bounce = [&](Batch& B, uint32_t depth) -> int {
         if (s->fail_at_bounce && --s->fail_at_bounce == 0) return fail(3, "render: injected failure (option fail_at_bounce)");
         const uint32_t slot = depth % kRing, prev_slot = (depth + kRing - 1) % kRing;
-        unsigned long long* cnt = B.count + 2 * slot;
-        const unsigned long long* prev = depth ? B.count + 2 * prev_slot : nullptr;
-        unsigned long long* clear = B.count + 2 * ((depth + kClearAhead) % kRing);
+        unsigned long long* cnt = B.count + kSlotWords * slot;
+        const unsigned long long* prev = depth ? B.count + kSlotWords * prev_slot : nullptr;
+        unsigned long long* clear = B.count + kSlotWords * ((depth + kClearAhead) % kRing);
+        const uint32_t parts = 1u << B.F.part_log2;
         B.tags[slot] = ++s->tag;     // bounce `depth` is published under this tag by the next extend launch
         const bool wide = B.bound >= kNarrowBelow;
         const uint32_t tile = wide ? kTileWide : kBlock;
         auto extend = [&](auto kernel) {
-            launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3((B.bound + tile - 1) / tile), dim3(kBlock), s->view, B.F, B.rad, B.qa,
-                      prev, B.bound, B.qb, B.hits, cnt, clear, B.L->h_count + 2 * prev_slot, B.tags[prev_slot], n_bins,
+            // (the first bounce generates its rays from the batch's path ids; later ones read their partition's rays)
+            const uint32_t grid = depth == 0 ? (B.bound + tile - 1) / tile : parts * ((B.pbound + tile - 1) / tile);
+            launch_on(s, B.L->stream, ORION_KERNEL_CLOSEST_HIT, 0, kernel, dim3(grid), dim3(kBlock), s->view, B.F, B.rad, B.qa,
+                      prev, depth == 0 ? B.bound : B.pbound, B.qb, B.hits, cnt, clear, B.L->h_count + 4 * prev_slot, B.tags[prev_slot], n_bins,
                       static_cast<const float4*>(B.L->pre_hits.p), static_cast<uint32_t*>(B.L->pre_work.p), static_cast<const float2*>(B.L->jitter.p),
                       static_cast<unsigned long long*>(B.L->hit_mask.p));
         };
@@ -960,10 +994,13 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         }
         with_mode(mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
-            auto shade = point ? k_shade<MODE, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf : k_shade<MODE, false>);
+            // (a batch's first bounce leaves path ids instead of whole records: the kernels' FIRST forms)
+            auto shade = depth == 0 ? (point ? k_shade<MODE, true, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf<true> : k_shade<MODE, false, true>))
+                                    : (point ? k_shade<MODE, true, false> : (MODE == MODE_WAVE ? k_shade_wave_brdf<false> : k_shade<MODE, false, false>));
             // (the first vertices of a large scene left to choose: their shadow rays walk together, see the kernel)
             if (MODE == MODE_WIDE && point && depth == 0 && s->traversal == 0 && s->wave_ok) shade = k_shade_wide_point0;
-            launch_on(s, B.L->stream, ORION_KERNEL_SHADE, 0, shade, dim3(grid_for(B.bound)), dim3(kBlock), s->view, B.F, depth, B.qb, cnt, B.hits, B.qa, cnt + 1, B.rad);
+            launch_on(s, B.L->stream, ORION_KERNEL_SHADE, 0, shade, dim3(parts * grid_for(B.pbound)), dim3(kBlock), s->view, B.F, depth, B.qb, cnt, B.hits, B.qa, cnt + 1, B.rad,
+                      static_cast<const float2*>(B.L->jitter.p));
         });
         HIP_TRY(hipGetLastError());
         B.launched = depth + 1;
@@ -971,8 +1008,8 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     };
     auto consume = [&](Batch& B) -> int { // read the counters of bounce `consumed`
         const uint32_t slot = B.consumed % kRing;
-        uint32_t h[2];
-        if (int rc = await_counters(B.L->stream, B.L->h_count + 2 * slot, B.tags[slot], h)) return rc;
+        uint32_t h[3];
+        if (int rc = await_counters(B.L->stream, B.L->h_count + 4 * slot, B.tags[slot], h)) return rc;
         if (s->profiling) {
             s->stats[ORION_KERNEL_CLOSEST_HIT].items += B.rays_in;
             s->stats[ORION_KERNEL_SHADE].items += h[0];
@@ -980,6 +1017,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             s->stats[ORION_KERNEL_SHADOW].items += (uint64_t)h[0] * rays_per_vertex;
         }
         B.rays_in = h[1];
+        B.pbound = h[2];
         B.consumed++;
         return 0;
     };
@@ -1013,7 +1051,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
                     // rays it starts from are the ones the last shade launch emitted, at most `bound`.
                     if (tail_ok && cur.bound <= s->tail_paths && cur.launched <= p->max_depth) {
                         launch_on(s, cur.L->stream, ORION_KERNEL_TAIL, cur.bound, point ? k_tail<true> : k_tail<false>, dim3((cur.bound + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
-                                  s->view, cur.F, cur.launched, cur.qa, cur.count + 2 * ((cur.launched - 1) % kRing), cur.rad);
+                                  s->view, cur.F, cur.launched, cur.qa, cur.count + kSlotWords * ((cur.launched - 1) % kRing), cur.rad);
                         HIP_TRY(hipGetLastError());
                         break;
                     }
@@ -1021,7 +1059,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             }
             if (s->profiling) {   // the statistics want every bounce; the last one has no extend launch after it
                 const uint32_t last = (cur.launched - 1) % kRing;
-                hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, cur.L->stream, cur.count + 2 * last, cur.L->h_count + 2 * last, cur.tags[last]);
+                hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, cur.L->stream, cur.count + kSlotWords * last, cur.L->h_count + 4 * last, cur.tags[last], cur.F.part_log2);
                 while (cur.consumed < cur.launched) if (int rc = consume(cur)) return rc;
             }
             // The accumulator takes the batches' sums in ascending sample order, whichever lane they ran on.

@@ -496,6 +496,10 @@ struct Queues {
     float4* T;    // throughput.xyz, absolute sample index (RNG counter word 1)
 };
 
+// The vertex records of a batch's FIRST bounce hold the path id only (the rest follows from it): a packed array of words in
+// the memory of the origin records.
+__device__ __forceinline__ uint32_t* first_vertex_ids(const Queues& q) { return reinterpret_cast<uint32_t*>(q.o); }
+
 // Path ids of a batch run pixel by pixel, the batch's samples of one pixel side by side: the 64 lanes of a wave
 // that generates camera rays hold (up to) 64 samples of ONE pixel, rays that differ by a fraction of a pixel.  The
 // wave-synchronous walk costs the union of its lanes' paths, and so do the shade kernel's in-place shadow rays:
@@ -536,6 +540,14 @@ __device__ __forceinline__ void primary_ray(const FrameParams& F, uint32_t pid, 
     float jx, jy;
     sample_jitter(F, sample, jx, jy);
     primary_ray_at(F, pid, px, py, sample, jx, jy, qo, qd, qT);
+}
+
+// Primary ray of path `pid` with the sample's jitter taken from the batch's table (the same numbers as primary_ray's).
+__device__ __forceinline__ void primary_ray_table(const FrameParams& F, const float2* __restrict__ jitter, uint32_t pid, float4& qo, float4& qd, float4& qT) {
+    uint32_t pixel, sample, px, py;
+    path_pixel(F, pid, pixel, sample, px, py);
+    const float2 j = jitter[sample - F.spp_begin];
+    primary_ray_at(F, pid, px, py, sample, j.x, j.y, qo, qd, qT);
 }
 
 // The batch's jitters, one per sample (k_jitter fills the table before the batch's first launch).
@@ -611,14 +623,22 @@ constexpr uint32_t kMaxBins = 64;
 // pinned mirror (`publish`), where the host polls for them.  Each count travels with the tag in
 // one 64-bit store, so the host needs no ordering between the two (and the kernel no fence,
 // which at system scope would write back and invalidate the L2).
-__device__ __forceinline__ void publish_counters(const unsigned long long* cnt, unsigned long long* publish, uint32_t tag) {
+// Published per bounce: the vertices and the rays of all partitions together, and the largest partition's rays
+// (the bound the host sizes the next grids from).
+__device__ __forceinline__ void publish_counters(const unsigned long long* cnt, unsigned long long* publish, uint32_t tag, uint32_t part_log2) {
     const unsigned long long hi = (unsigned long long)tag << 32;
-    __hip_atomic_store(publish, hi | (uint32_t)cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(publish + 1, hi | (uint32_t)cnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t vertices = 0, rays = 0, most = 0;
+    for (uint32_t k = 0; k < (1u << part_log2); k++) {
+        const uint32_t r = (uint32_t)cnt[k * kPartWords + 1];
+        vertices += (uint32_t)cnt[k * kPartWords]; rays += r; most = max(most, r);
+    }
+    __hip_atomic_store(publish, hi | vertices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(publish + 1, hi | rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(publish + 2, hi | most, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void k_publish(const unsigned long long* cnt, unsigned long long* publish, uint32_t tag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) publish_counters(cnt, publish, tag);
+__global__ void k_publish(const unsigned long long* cnt, unsigned long long* publish, uint32_t tag, uint32_t part_log2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) publish_counters(cnt, publish, tag, part_log2);
 }
 
 // The closest hits of a bounce's rays on a large scene, found the way the ray queries find theirs: the
@@ -651,15 +671,20 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
     __shared__ uint32_t s_cnt[kMaxBins];
     __shared__ uint32_t s_off[kMaxBins];
     __shared__ uint32_t s_base;
-    const uint32_t tile0 = blockIdx.x * kTile;
+    // The block's partition: its input (unless the rays are generated here, from path ids that run through the whole
+    // batch), its counters and its output.  n_bound and the counts are per partition (GEN: the batch's paths).
+    const uint32_t part = blockIdx.x & ((1u << F.part_log2) - 1u);
+    const uint32_t qoff = part * F.part_stride;
+    const uint32_t tile0 = (GEN ? blockIdx.x : blockIdx.x >> F.part_log2) * kTile;
+    counter += part * kPartWords;
     uint32_t n = n_bound;
-    if (prev) { const unsigned long long m = prev[1]; if (m < n) n = (uint32_t)m; }
+    if (prev) { const unsigned long long m = prev[part * kPartWords + 1]; if (m < n) n = (uint32_t)m; }
     // Block 0's housekeeping stores come after the traversal on purpose: a store ahead of the
     // scene loads would keep the compiler from issuing them as scalar loads.
     auto housekeeping = [&]() {
         if (blockIdx.x != 0) return;
-        if (threadIdx.x < 2) clear[threadIdx.x] = 0ull;
-        if (prev && threadIdx.x == 0) publish_counters(prev, publish, tag);
+        if (threadIdx.x < (2u << F.part_log2)) clear[(threadIdx.x >> 1) * kPartWords + (threadIdx.x & 1u)] = 0ull;
+        if (prev && threadIdx.x == 0) publish_counters(prev, publish, tag, F.part_log2);
         if (MODE == MODE_PRE && threadIdx.x < kWorkParts) pre_work[kWorkCounters + 16u * threadIdx.x] = 0u;   // k_extend_wide's grab counters, for its next launch
     };
     if (tile0 >= n) { housekeeping(); return; }
@@ -675,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
         if (active && MODE != MODE_PRE) {
             float4 a, b, c;
             if (GEN) primary_ray_tile(F, gen, jitter, i, slot, a, b, c);
-            else { a = qin.o[i]; b = qin.d[i]; }
+            else { a = qin.o[qoff + i]; b = qin.d[qoff + i]; }
             o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
         }
         HitRec h = miss_rec();
@@ -714,13 +739,16 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
         const uint32_t gtri = __float_as_uint(h.w);
         if (gtri != kInvalid) {
             const uint32_t i = tile0 + slot;
-            const uint32_t dst = base + s_off[min(gtri, n_bins - 1u)] + s_rank[slot];
-            float4 a, b, c;
-            if (GEN) primary_ray_tile(F, gen, jitter, i, slot, a, b, c);
-            else { a = qin.o[i]; b = qin.d[i]; c = qin.T[i]; }
-            qout.o[dst] = a;
-            qout.d[dst] = b;
-            qout.T[dst] = c;
+            const uint32_t dst = qoff + base + s_off[min(gtri, n_bins - 1u)] + s_rank[slot];
+            if (GEN) {
+                // A first vertex's ray, throughput and ids follow from its path id (= i): 4 bytes instead of 48 written
+                // here and read by the shade launch, which computes them again (first_vertex_ids).
+                first_vertex_ids(qout)[dst] = i;
+            } else {
+                qout.o[dst] = qin.o[qoff + i];
+                qout.d[dst] = qin.d[qoff + i];
+                qout.T[dst] = qin.T[qoff + i];
+            }
             reinterpret_cast<float4*>(hits)[dst] = h;
         }
     }
@@ -774,9 +802,24 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
                     light_point(S, lm, r, target, lint);
                     sd = target - hitPos;
                 }
+                // A sample whose term is surely zero is not traced.  The term is a product of finite numbers with
+                // max(f1 * f2, 0), f1 = dot(normal, l), f2 = dot(light's normal at the hit, -l), l = sd normalised
+                // (color_brdf).  On a light with one normal N for all its vertices (Mesh::flat) the interpolated,
+                // normalised normal is N's unit vector to within 1e-6 per component, so with a = dot(normal, sd) and
+                // b = dot(N, sd) both beyond 1e-4 |sd| -- a hundred times the rounding of either dot product -- f1 has
+                // a's sign and f2 the opposite of b's: if a and b agree in sign the product is negative, the term is a
+                // zero vector and adding it leaves the sum's bits alone.  (NaN or overflow anywhere fails the
+                // comparisons and the ray is traced.)
+                bool need = live;
+                if (lm.flat) {
+                    const float a = fmaf(normal.z, sd.z, fmaf(normal.y, sd.y, normal.x * sd.x));
+                    const float b = fmaf(lm.flat_n[2], sd.z, fmaf(lm.flat_n[1], sd.y, lm.flat_n[0] * sd.x));
+                    const float lim = 1e-8f * fmaf(sd.z, sd.z, fmaf(sd.y, sd.y, sd.x * sd.x));
+                    if (a * b > 0.0f && fminf(a * a, b * b) > lim) need = false;
+                }
                 HitRec h2 = miss_rec();
-                traverse<MODE, false>(S, biased, sd, h2, live);
-                if (live && h2.gtri != kInvalid) {
+                traverse<MODE, false>(S, biased, sd, h2, need);
+                if (need && h2.gtri != kInvalid) {
                     const Surface s2 = surface_at(S, h2.gtri, h2.u, h2.v);
                     if (s2.mesh == lmesh) {   // the sample is visible iff the closest hit is the light itself
                         const V3 lcol = tex_fetch(S, lm.tex[kTexEmissive], s2.tu, s2.tv);
@@ -798,10 +841,14 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
                 unsafeAtomicAdd(rp, acc.x); unsafeAtomicAdd(rp + 1, acc.y); unsafeAtomicAdd(rp + 2, acc.z);
             }
 #else
-            if (writer) {   // (a path's first vertex finds no sum yet; nobody reads the slots of the paths that miss)
+            const V3 term = T * color;
+            // A path's first vertex finds no sum yet (nobody reads the slots of the paths that miss).  A later vertex that
+            // gathers no light -- every sample occluded or facing away -- would add zeros to a sum that is no negative
+            // zero, since it began as 0 + x: the slot keeps its bits untouched, 32 bytes of scattered traffic less.
+            if (writer && (depth == 0 || term.x != 0.0f || term.y != 0.0f || term.z != 0.0f)) {
                 float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (depth != 0) r0 = rad[pid];
-                const V3 acc = mk(r0.x, r0.y, r0.z) + T * color;
+                const V3 acc = mk(r0.x, r0.y, r0.z) + term;
                 rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
             }
 #endif
@@ -865,27 +912,33 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
 
 // Input: the `*n_live` vertex records k_extend left (every one of them a hit); the grid is sized
 // for the ray count, blocks past the live count leave at once.
-template <int MODE, bool POINT, int SHADOW = MODE>
+// FIRST: the batch's first bounce, whose records are path ids (k_extend<.., GEN>); `jitter` is the batch's table.
+template <int MODE, bool POINT, int SHADOW, bool FIRST>
 __device__ __forceinline__ void shade_block(const SceneView& S, const FrameParams& F, uint32_t depth, Queues qin,
                                             const unsigned long long* __restrict__ n_live, const HitRec* __restrict__ hits,
-                                            Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad) {
-    const uint32_t n = (uint32_t)*n_live;
-    if (blockIdx.x * kBlock >= n) return;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+                                            Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad,
+                                            const float2* __restrict__ jitter) {
+    const uint32_t part = blockIdx.x & ((1u << F.part_log2) - 1u), blk = blockIdx.x >> F.part_log2;   // (see k_extend)
+    const uint32_t qoff = part * F.part_stride;
+    const uint32_t n = (uint32_t)n_live[part * kPartWords];
+    if (blk * kBlock >= n) return;
+    const uint32_t i = blk * kBlock + threadIdx.x;
     const bool live = i < n;
     V3 o = splat(0.0f), d = splat(1.0f), T = splat(0.0f);
     uint32_t pid = 0, pixel = 0, sample = 0;
     HitRec h = miss_rec();
     if (live) {
-        const float4 a = qin.o[i], b = qin.d[i], c = qin.T[i];
+        float4 a, b, c;
+        if (FIRST) primary_ray_table(F, jitter, first_vertex_ids(qin)[qoff + i], a, b, c);
+        else { a = qin.o[qoff + i]; b = qin.d[qoff + i]; c = qin.T[qoff + i]; }
         o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z); T = mk(c.x, c.y, c.z);
         pid = __float_as_uint(a.w); pixel = __float_as_uint(b.w); sample = __float_as_uint(c.w);
-        const float4 hr = reinterpret_cast<const float4*>(hits)[i];
+        const float4 hr = reinterpret_cast<const float4*>(hits)[qoff + i];
         h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
     }
     V3 biased, next_d, next_T;
     const bool cont = shade_core<MODE, POINT, SHADOW>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
-    const uint32_t slot = queue_slot(cont, false, out_count);
+    const uint32_t slot = qoff + queue_slot(cont, false, out_count + part * kPartWords);
     if (cont) {
         qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
         qout.d[slot] = make_float4(next_d.x, next_d.y, next_d.z, __uint_as_float(pixel));
@@ -893,12 +946,12 @@ __device__ __forceinline__ void shade_block(const SceneView& S, const FrameParam
     }
 }
 
-template <int MODE, bool POINT>
+template <int MODE, bool POINT, bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, uint32_t depth, Queues qin,
                                                   const unsigned long long* __restrict__ n_live,
                                                   const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
-                                                  float4* __restrict__ rad) {
-    shade_block<MODE, POINT>(S, F, depth, qin, n_live, hits, qout, out_count, rad);
+                                                  float4* __restrict__ rad, const float2* __restrict__ jitter) {
+    shade_block<MODE, POINT, MODE, FIRST>(S, F, depth, qin, n_live, hits, qout, out_count, rad, jitter);
 }
 
 // The first vertices of a point-light frame on a large scene: a wave holds samples of one pixel (path_pixel), points a
@@ -909,17 +962,19 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, FrameParams F, ui
 #endif
 __global__ __launch_bounds__(kBlock) void k_shade_wide_point0(SceneView S, FrameParams F, uint32_t depth, Queues qin, const unsigned long long* __restrict__ n_live,
                                                               const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count,
-                                                              float4* __restrict__ rad) {
-    shade_block<MODE_WIDE, true, ORION_SHADOW0_MODE>(S, F, depth, qin, n_live, hits, qout, out_count, rad);
+                                                              float4* __restrict__ rad, const float2* __restrict__ jitter) {
+    shade_block<MODE_WIDE, true, ORION_SHADOW0_MODE, true>(S, F, depth, qin, n_live, hits, qout, out_count, rad, jitter);
 }
 
 // The wave-synchronous BRDF form, the kernel a Cornell-class frame spends two thirds of its time
 // in, is held to 72 VGPRs: 7 waves per SIMD instead of 6 is worth 12 % of the step, and with the
 // hand-scheduled walk the compiler reaches it without spilling a vector register.
+template <bool FIRST>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7)))
 void k_shade_wave_brdf(SceneView S, FrameParams F, uint32_t depth, Queues qin, const unsigned long long* __restrict__ n_live,
-                       const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad) {
-    shade_block<MODE_WAVE, false>(S, F, depth, qin, n_live, hits, qout, out_count, rad);
+                       const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad,
+                       const float2* __restrict__ jitter) {
+    shade_block<MODE_WAVE, false, MODE_WAVE, FIRST>(S, F, depth, qin, n_live, hits, qout, out_count, rad, jitter);
 }
 
 // The last bounces of a batch, one PATH per wave.  Once a few thousand rays are left, a bounce's
@@ -935,9 +990,15 @@ void k_shade_wave_brdf(SceneView S, FrameParams F, uint32_t depth, Queues qin, c
 template <bool POINT>
 __global__ __launch_bounds__(kBlock) void k_tail(SceneView S, FrameParams F, uint32_t depth0, Queues qin,
                                                  const unsigned long long* __restrict__ prev, float4* __restrict__ rad) {
-    const uint32_t n = (uint32_t)prev[1];
-    const uint32_t path = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (path >= n) return;   // whole waves leave: every lane of a wave has the same path
+    uint32_t path = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // counted through the partitions' rays, one partition after the other
+    uint32_t part = 0;
+    for (; part < (1u << F.part_log2); part++) {
+        const uint32_t c = (uint32_t)prev[part * kPartWords + 1];
+        if (path < c) break;
+        path -= c;
+    }
+    if (part == (1u << F.part_log2)) return;   // whole waves leave: every lane of a wave has the same path
+    path += part * F.part_stride;
     const float4 a = qin.o[path], b = qin.d[path], c = qin.T[path];
     V3 o = mk(a.x, a.y, a.z), d = mk(b.x, b.y, b.z), T = mk(c.x, c.y, c.z);
     const uint32_t pid = __float_as_uint(a.w), pixel = __float_as_uint(b.w), sample = __float_as_uint(c.w);
