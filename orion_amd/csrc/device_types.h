@@ -116,7 +116,18 @@ struct Mesh {
     // not finite.
     float flat_n[3];
     uint32_t flat;
+    // What the shade kernel would otherwise reach through chains of dependent loads (mesh -> texture table -> texel;
+    // hit -> attributes; triangle index -> slot -> triangle), each link a round trip a wave waits for:
+    // the colour of a 1x1 diffuse / emissive texture (every solid colour; Texture::color maps any uv to its one texel),
+    // the light's normal as its vertices hold it (one_normal: all of them hold the same), and where the light's
+    // triangles stand once more in their original order behind the triangle array (light sampling picks by that order).
+    float kd[3]; uint32_t kd_solid;
+    float ke[3]; uint32_t ke_solid;
+    float raw_n[3]; uint32_t one_normal;
+    uint32_t light_tris;   // index into SceneView::tris
+    uint32_t pad_[3];
 };
+static_assert(sizeof(Mesh) == 112, "Mesh layout");
 
 // Everything a kernel needs, passed by value.
 struct SceneView {

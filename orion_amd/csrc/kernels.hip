@@ -108,6 +108,7 @@ struct OrionScene {
     std::vector<void*> owned;         // device allocations of the flattened scene
     std::vector<uint32_t> mesh_tri_base;
     uint32_t n_nodes = 0, n_tris = 0;
+    bool solid = false;   // solid diffuse and emissive colours everywhere, every light's vertices share one normal (Mesh::kd_solid ...)
     // The hand-scheduled wave-synchronous walk steps through the node and triangle arrays with 32-bit byte
     // offsets (intersect.h): scenes whose arrays reach 4 GiB never take it.
     bool wave_ok = true;
@@ -516,16 +517,19 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         const bool is_emissive = md.emissive_color[0] != 0.0f || md.emissive_color[1] != 0.0f || md.emissive_color[2] != 0.0f;
         if (is_emissive && ntri) emissive.push_back(mi);
         dm.flat = 0; dm.flat_n[0] = dm.flat_n[1] = dm.flat_n[2] = 0.0f;
+        dm.one_normal = 0; dm.raw_n[0] = dm.raw_n[1] = dm.raw_n[2] = 0.0f;
+        dm.light_tris = 0;
         if (is_emissive && ntri) {   // one normal for the whole light, finite intensities: see Mesh::flat
             const float* n0 = attrs[tri_base].n0;
-            bool flat = true;
-            for (uint32_t o = 0; o < ntri && flat; o++) {
+            bool one = true, finite = true;
+            for (uint32_t o = 0; o < ntri; o++) {
                 const TriAttr& a = attrs[tri_base + o];
-                flat = !std::memcmp(a.n0, n0, 12) && !std::memcmp(a.n1, n0, 12) && !std::memcmp(a.n2, n0, 12) &&
-                       std::isfinite(tris[slot_base + o].light_intensity);
+                one = one && !std::memcmp(a.n0, n0, 12) && !std::memcmp(a.n1, n0, 12) && !std::memcmp(a.n2, n0, 12);
+                finite = finite && std::isfinite(tris[slot_base + o].light_intensity);
             }
+            if (one) { dm.one_normal = 1; std::memcpy(dm.raw_n, n0, 12); }
             const double len = std::sqrt((double)n0[0] * n0[0] + (double)n0[1] * n0[1] + (double)n0[2] * n0[2]);
-            if (flat && std::isfinite(len) && len > 1e-18) {
+            if (one && finite && std::isfinite(len) && len > 1e-18) {
                 for (int c = 0; c < 3; c++) dm.flat_n[c] = (float)(n0[c] / len);
                 dm.flat = 1;
             }
@@ -595,6 +599,27 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
 
     if (!texels_finite)
         for (Mesh& dm : dmeshes) dm.flat = 0;
+    for (Mesh& dm : dmeshes) {   // solid colours, as Texture::color would return them
+        auto solid = [&](uint32_t t, float* rgb) -> uint32_t {
+            const OrionTextureDesc& td = textures[t];
+            if (td.width != 1 || td.height != 1) return 0;
+            if (td.format == ORION_TEX_RGB_F32) { std::memcpy(rgb, td.texels, 12); return 1; }
+            const uint8_t* q = static_cast<const uint8_t*>(td.texels);
+            if (td.format == ORION_TEX_GRAY_U8) { rgb[0] = rgb[1] = rgb[2] = (float)q[0] / 255.0f; return 1; }
+            for (int c = 0; c < 3; c++) rgb[c] = (float)q[c] / 255.0f;
+            return 1;
+        };
+        dm.kd_solid = n_textures ? solid(dm.tex[1], dm.kd) : 0;
+        dm.ke_solid = n_textures ? solid(dm.tex[3], dm.ke) : 0;
+    }
+    // The lights' triangles once more, in their original order, behind the array's spare record.
+    std::vector<Tri> tris_up = tris;
+    tris_up.push_back(Tri{});
+    for (uint32_t mi : emissive) {
+        dmeshes[mi].light_tris = (uint32_t)tris_up.size();
+        for (uint32_t o = 0; o < dmeshes[mi].n_tri; o++) tris_up.push_back(tris[slot_of[dmeshes[mi].tri_base + o]]);
+    }
+    if (tris_up.size() >= 0xFFFFFFFFull) return fail(1, "scene_create: too many triangles");
 
     // ---- upload ----------------------------------------------------------------
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return fail(2, "no HIP device"); }
@@ -627,10 +652,9 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
                 for (int a = 0; a < 3; a++) { all.lo[a] = std::fmin(all.lo[a], nodes[w[0]].lo[a]); all.hi[a] = std::fmax(all.hi[a], nodes[w[0]].hi[a]); }
         nodes.push_back(all);
     }
-    tris.push_back(Tri{});
     if ((rc = upload(s, nodes, &v.nodes))) return bail(rc);
-    if ((rc = upload(s, tris, &v.tris))) return bail(rc);
-    nodes.pop_back(); tris.pop_back();
+    if ((rc = upload(s, tris_up, &v.tris))) return bail(rc);
+    nodes.pop_back();
     if ((rc = upload(s, attrs, &v.attrs))) return bail(rc);
     if ((rc = upload(s, slot_of, &v.slot_of))) return bail(rc);
     if ((rc = upload(s, dmeshes, &v.meshes))) return bail(rc);
@@ -666,7 +690,10 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         v.dir_bound = (float)(bound * (1.0 - 1e-6));
     }
     s->n_nodes = v.n_nodes; s->n_tris = v.n_tris;
-    s->wave_ok = (uint64_t)(tris.size() + 1) * sizeof(Tri) < (1ull << 32) && (uint64_t)(nodes.size() + 1) * sizeof(Node) < (1ull << 32);   // (+ the spare records)
+    s->solid = n_meshes != 0;
+    for (const Mesh& dm : dmeshes) s->solid = s->solid && dm.kd_solid && dm.ke_solid;
+    for (uint32_t mi : emissive) s->solid = s->solid && dmeshes[mi].one_normal;
+    s->wave_ok = (uint64_t)tris_up.size() * sizeof(Tri) < (1ull << 32) && (uint64_t)(nodes.size() + 1) * sizeof(Node) < (1ull << 32);   // (+ the spare records)
     {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0 &&
@@ -995,8 +1022,8 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         with_mode(mode, [&](auto M) {
             constexpr int MODE = decltype(M)::value;
             // (a batch's first bounce leaves path ids instead of whole records: the kernels' FIRST forms)
-            auto shade = depth == 0 ? (point ? k_shade<MODE, true, true> : (MODE == MODE_WAVE ? k_shade_wave_brdf<true> : k_shade<MODE, false, true>))
-                                    : (point ? k_shade<MODE, true, false> : (MODE == MODE_WAVE ? k_shade_wave_brdf<false> : k_shade<MODE, false, false>));
+            auto shade = depth == 0 ? (point ? k_shade<MODE, true, true> : (MODE == MODE_WAVE ? (s->solid ? k_shade_wave_brdf<true, true> : k_shade_wave_brdf<true, false>) : k_shade<MODE, false, true>))
+                                    : (point ? k_shade<MODE, true, false> : (MODE == MODE_WAVE ? (s->solid ? k_shade_wave_brdf<false, true> : k_shade_wave_brdf<false, false>) : k_shade<MODE, false, false>));
             // (the first vertices of a large scene left to choose: their shadow rays walk together, see the kernel)
             if (MODE == MODE_WIDE && point && depth == 0 && s->traversal == 0 && s->wave_ok) shade = k_shade_wide_point0;
             launch_on(s, B.L->stream, ORION_KERNEL_SHADE, 0, shade, dim3(parts * grid_for(B.pbound)), dim3(kBlock), s->view, B.F, depth, B.qb, cnt, B.hits, B.qa, cnt + 1, B.rad,

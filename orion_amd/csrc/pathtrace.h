@@ -760,7 +760,9 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
 // to rad[pid] (lanes with `writer` set do the store) and returns whether the path goes on, with
 // the next ray's origin (the biased hit point), direction and throughput.
 // SHADOW: the walk of the point lights' shadow rays (MODE unless the caller knows better).
-template <int MODE, bool POINT, int SHADOW = MODE>
+// SOLID: the scene has solid colours only and lights whose vertices share one normal (OrionScene::solid): what the
+// general form reaches through chains of dependent loads comes from the mesh records (Mesh::kd and below).
+template <int MODE, bool POINT, int SHADOW = MODE, bool SOLID = false>
 __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams& F, uint32_t depth, bool live, bool writer,
                                            V3 o, V3 d, V3 T, uint32_t pid, uint32_t pixel, uint32_t sample, const HitRec& h,
                                            float4* __restrict__ rad, V3& biased, V3& next_d, V3& next_T) {
@@ -776,9 +778,10 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
         hitPos = o + d * h.t;
         biased = hitPos + normal * bias;
         if (depth == 0) {   // primary ray sees an emissive surface (orion/raytracer.cpp:127-128)
-            const Mesh m = S.meshes[mesh_id];
+            const Mesh& m = S.meshes[mesh_id];
             const float dn = dot(normalize(d), -normal);
-            color = (tex_fetch(S, m.tex[kTexEmissive], tu, tv) * m.area) * dn;
+            const V3 ke = SOLID ? ld3(m.ke) : tex_fetch(S, m.tex[kTexEmissive], tu, tv);
+            color = (ke * m.area) * dn;
         }
     }
 
@@ -788,7 +791,10 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
     if (!POINT) {
         // Direct light: light_samples points on every emissive mesh (orion/raytracer.cpp:133-159)
         V3 kd = splat(0.0f);
-        if (live) kd = tex_fetch(S, S.meshes[mesh_id].tex[kTexDiffuse], tu, tv);
+        if (live) {
+            const Mesh& m = S.meshes[mesh_id];
+            kd = SOLID ? ld3(m.kd) : tex_fetch(S, m.tex[kTexDiffuse], tu, tv);
+        }
         const float inv_ls = F.inv_light_samples;
         for (uint32_t e = 0; e < S.n_emissive; e++) {
             const uint32_t lmesh = S.emissive[e];
@@ -819,11 +825,22 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
                 }
                 HitRec h2 = miss_rec();
                 traverse<MODE, false>(S, biased, sd, h2, need);
-                if (need && h2.gtri != kInvalid) {
-                    const Surface s2 = surface_at(S, h2.gtri, h2.u, h2.v);
-                    if (s2.mesh == lmesh) {   // the sample is visible iff the closest hit is the light itself
-                        const V3 lcol = tex_fetch(S, lm.tex[kTexEmissive], s2.tu, s2.tv);
-                        contrib = contrib + color_brdf(kd, normal, hitPos, target, lcol, lint, normalize(s2.normal));
+                if (need && h2.gtri != kInvalid) {   // the sample is visible iff the closest hit is the light itself
+                    if (SOLID) {
+                        // A light of one colour whose vertices share one normal: the hit's mesh follows from its triangle
+                        // id, the normal there is surface_at's weighted sum of that one vector, and nothing is loaded.
+                        if (h2.gtri - lm.tri_base < lm.n_tri) {
+                            const V3 N = ld3(lm.raw_n);
+                            const float w = 1.0f - h2.u - h2.v;
+                            const V3 n2 = (N * w + N * h2.u) + N * h2.v;
+                            contrib = contrib + color_brdf(kd, normal, hitPos, target, ld3(lm.ke), lint, normalize(n2));
+                        }
+                    } else {
+                        const Surface s2 = surface_at(S, h2.gtri, h2.u, h2.v);
+                        if (s2.mesh == lmesh) {
+                            const V3 lcol = tex_fetch(S, lm.tex[kTexEmissive], s2.tu, s2.tv);
+                            contrib = contrib + color_brdf(kd, normal, hitPos, target, lcol, lint, normalize(s2.normal));
+                        }
                     }
                 }
             }
@@ -913,7 +930,7 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
 // Input: the `*n_live` vertex records k_extend left (every one of them a hit); the grid is sized
 // for the ray count, blocks past the live count leave at once.
 // FIRST: the batch's first bounce, whose records are path ids (k_extend<.., GEN>); `jitter` is the batch's table.
-template <int MODE, bool POINT, int SHADOW, bool FIRST>
+template <int MODE, bool POINT, int SHADOW, bool FIRST, bool SOLID = false>
 __device__ __forceinline__ void shade_block(const SceneView& S, const FrameParams& F, uint32_t depth, Queues qin,
                                             const unsigned long long* __restrict__ n_live, const HitRec* __restrict__ hits,
                                             Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad,
@@ -937,7 +954,7 @@ __device__ __forceinline__ void shade_block(const SceneView& S, const FrameParam
         h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
     }
     V3 biased, next_d, next_T;
-    const bool cont = shade_core<MODE, POINT, SHADOW>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
+    const bool cont = shade_core<MODE, POINT, SHADOW, SOLID>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
     const uint32_t slot = qoff + queue_slot(cont, false, out_count + part * kPartWords);
     if (cont) {
         qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
@@ -969,12 +986,12 @@ __global__ __launch_bounds__(kBlock) void k_shade_wide_point0(SceneView S, Frame
 // The wave-synchronous BRDF form, the kernel a Cornell-class frame spends two thirds of its time
 // in, is held to 72 VGPRs: 7 waves per SIMD instead of 6 is worth 12 % of the step, and with the
 // hand-scheduled walk the compiler reaches it without spilling a vector register.
-template <bool FIRST>
+template <bool FIRST, bool SOLID>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7)))
 void k_shade_wave_brdf(SceneView S, FrameParams F, uint32_t depth, Queues qin, const unsigned long long* __restrict__ n_live,
                        const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad,
                        const float2* __restrict__ jitter) {
-    shade_block<MODE_WAVE, false, MODE_WAVE, FIRST>(S, F, depth, qin, n_live, hits, qout, out_count, rad, jitter);
+    shade_block<MODE_WAVE, false, MODE_WAVE, FIRST, SOLID>(S, F, depth, qin, n_live, hits, qout, out_count, rad, jitter);
 }
 
 // The last bounces of a batch, one PATH per wave.  Once a few thousand rays are left, a bounce's

@@ -162,8 +162,7 @@ __device__ __forceinline__ V3 color_phong(V3 ka, V3 kd, V3 ks, float shininess, 
 __device__ __forceinline__ void light_point(const SceneView& S, const Mesh& lm, Words4 r, V3& point, float& intensity) {
     // x % n without the division when n is a power of two (same value)
     const uint32_t ri = (lm.n_tri & (lm.n_tri - 1u)) == 0u ? (r.w[0] & (lm.n_tri - 1u)) : (r.w[0] % lm.n_tri);
-    const uint32_t slot = S.slot_of[lm.tri_base + ri];
-    const float4* tp = reinterpret_cast<const float4*>(S.tris + slot);
+    const float4* tp = reinterpret_cast<const float4*>(S.tris + lm.light_tris + ri);   // (the light's triangles in their original order)
     const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
     const V3 v0 = mk(T0.x, T0.y, T0.z), e1 = mk(T1.x, T1.y, T1.z), e2 = mk(T2.x, T2.y, T2.z);
     intensity = T2.w;
