@@ -196,7 +196,7 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *                 per stream; a render call takes fewer where the device's free memory asks for it)
  *   "overlap_below" a render call of several batches starts the next batch on a second
  *                 stream (with queues of its own) once the current batch has fewer rays
- *                 than this left (default 32 Mi; 0 = one batch at a time, half the memory)
+ *                 than this left (default 128 Mi; 0 = one batch at a time, half the memory)
  *   "draw_rays"   1 (default): on scenes that walk the 4-wide tree, the closest hits of bounce rays are found
  *                 by waves that draw rays from the queue as their lanes finish; 0: four rays per thread
  *   "wave_ahead"  1: the wave-synchronous walk of a large scene's camera rays asks for the next node and the next

@@ -117,7 +117,7 @@ struct OrionScene {
     std::string wide_why_not;         // why the scene has no wide tree ("" if it has one)
     uint32_t tail_paths = 1u << 16;   // hand a batch's last paths to k_tail once this few are left
     uint64_t batch_paths = 256u << 20;    // paths in flight per batch (128 B of queues each; less where the device's free memory asks for it)
-    uint32_t overlap_below = 32u << 20;   // start the next batch on the other lane once this few rays are left (0: never)
+    uint32_t overlap_below = 128u << 20;   // start the next batch on the other lane once this few rays are left (0: never)
     uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
     uint64_t queue_budget = 0;            // bytes the render queues may take (0: three quarters of the device's free memory)
     bool draw_rays = true;                // large scenes: bounce rays are handed to lanes as they finish (k_extend_wide)

@@ -762,10 +762,15 @@ __global__ __launch_bounds__(kBlock) void k_extend(SceneView S, FrameParams F, f
 // SHADOW: the walk of the point lights' shadow rays (MODE unless the caller knows better).
 // SOLID: the scene has solid colours only and lights whose vertices share one normal (OrionScene::solid): what the
 // general form reaches through chains of dependent loads comes from the mesh records (Mesh::kd and below).
-template <int MODE, bool POINT, int SHADOW = MODE, bool SOLID = false>
+// PARK: the throughput and the path id, which nothing needs while the light samples are traced, wait in LDS meanwhile
+// (a slot per thread of the block) instead of in registers the walks would push out to scratch memory.
+// DEPTH0: 1 if the caller knows that depth is 0, 0 if it knows that it is not, -1 if it does not know.
+template <int MODE, bool POINT, int SHADOW = MODE, bool SOLID = false, bool PARK = false, int DEPTH0 = -1>
 __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams& F, uint32_t depth, bool live, bool writer,
                                            V3 o, V3 d, V3 T, uint32_t pid, uint32_t pixel, uint32_t sample, const HitRec& h,
                                            float4* __restrict__ rad, V3& biased, V3& next_d, V3& next_T) {
+    __shared__ float4 s_park[PARK ? kBlock : 1];
+    if (PARK) s_park[threadIdx.x] = make_float4(T.x, T.y, T.z, __uint_as_float(pid));
     const float bias = 1e-3f;
     V3 normal = splat(0.0f), hitPos = splat(0.0f), color = splat(0.0f);
     biased = splat(0.0f);
@@ -777,7 +782,7 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
         normal = normalize(sf.normal);
         hitPos = o + d * h.t;
         biased = hitPos + normal * bias;
-        if (depth == 0) {   // primary ray sees an emissive surface (orion/raytracer.cpp:127-128)
+        if (DEPTH0 == 1 || (DEPTH0 == -1 && depth == 0)) {   // primary ray sees an emissive surface (orion/raytracer.cpp:127-128)
             const Mesh& m = S.meshes[mesh_id];
             const float dn = dot(normalize(d), -normal);
             const V3 ke = SOLID ? ld3(m.ke) : tex_fetch(S, m.tex[kTexEmissive], tu, tv);
@@ -804,7 +809,11 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
                 V3 target = splat(0.0f), sd = splat(1.0f);
                 float lint = 0.0f;
                 if (live) {
-                    const Words4 r = philox4x32_10(pixel, sample, depth, e * F.light_samples + l, F.seed_lo, F.seed_hi);
+                    // (the counter words pass through an empty asm: left alone, the compiler computes the first round's
+                    // products of the loop's Philox blocks ahead of the loop and then spills them around the walks)
+                    uint32_t c0 = pixel, c1 = sample;
+                    asm volatile("" : "+v"(c0), "+v"(c1));
+                    const Words4 r = philox4x32_10(c0, c1, depth, e * F.light_samples + l, F.seed_lo, F.seed_hi);
                     light_point(S, lm, r, target, lint);
                     sd = target - hitPos;
                 }
@@ -846,6 +855,7 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
             }
             color = color + contrib * inv_ls;
         }
+        if (PARK) { const float4 k = s_park[threadIdx.x]; T = mk(k.x, k.y, k.z); pid = __float_as_uint(k.w); }
         if (live) {
 #if ORION_EXPERIMENT_NO_RAD == 1
             if (writer && color.x == 12345.0f) rad[pid] = make_float4(color.x, 0.0f, 0.0f, 0.0f);   // timing experiment: no radiance traffic
@@ -862,9 +872,10 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
             // A path's first vertex finds no sum yet (nobody reads the slots of the paths that miss).  A later vertex that
             // gathers no light -- every sample occluded or facing away -- would add zeros to a sum that is no negative
             // zero, since it began as 0 + x: the slot keeps its bits untouched, 32 bytes of scattered traffic less.
-            if (writer && (depth == 0 || term.x != 0.0f || term.y != 0.0f || term.z != 0.0f)) {
+            const bool first = DEPTH0 == 1 || (DEPTH0 == -1 && depth == 0);
+            if (writer && (first || term.x != 0.0f || term.y != 0.0f || term.z != 0.0f)) {
                 float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (depth != 0) r0 = rad[pid];
+                if (!first) r0 = rad[pid];
                 const V3 acc = mk(r0.x, r0.y, r0.z) + term;
                 rad[pid] = make_float4(acc.x, acc.y, acc.z, 0.0f);
             }
@@ -930,7 +941,7 @@ __device__ __forceinline__ bool shade_core(const SceneView& S, const FrameParams
 // Input: the `*n_live` vertex records k_extend left (every one of them a hit); the grid is sized
 // for the ray count, blocks past the live count leave at once.
 // FIRST: the batch's first bounce, whose records are path ids (k_extend<.., GEN>); `jitter` is the batch's table.
-template <int MODE, bool POINT, int SHADOW, bool FIRST, bool SOLID = false>
+template <int MODE, bool POINT, int SHADOW, bool FIRST, bool SOLID = false, bool PARK = false>
 __device__ __forceinline__ void shade_block(const SceneView& S, const FrameParams& F, uint32_t depth, Queues qin,
                                             const unsigned long long* __restrict__ n_live, const HitRec* __restrict__ hits,
                                             Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad,
@@ -954,7 +965,7 @@ __device__ __forceinline__ void shade_block(const SceneView& S, const FrameParam
         h.t = hr.x; h.u = hr.y; h.v = hr.z; h.gtri = __float_as_uint(hr.w);
     }
     V3 biased, next_d, next_T;
-    const bool cont = shade_core<MODE, POINT, SHADOW, SOLID>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
+    const bool cont = shade_core<MODE, POINT, SHADOW, SOLID, PARK, FIRST ? 1 : 0>(S, F, depth, live, true, o, d, T, pid, pixel, sample, h, rad, biased, next_d, next_T);
     const uint32_t slot = qoff + queue_slot(cont, false, out_count + part * kPartWords);
     if (cont) {
         qout.o[slot] = make_float4(biased.x, biased.y, biased.z, __uint_as_float(pid));
@@ -986,12 +997,15 @@ __global__ __launch_bounds__(kBlock) void k_shade_wide_point0(SceneView S, Frame
 // The wave-synchronous BRDF form, the kernel a Cornell-class frame spends two thirds of its time
 // in, is held to 72 VGPRs: 7 waves per SIMD instead of 6 is worth 12 % of the step, and with the
 // hand-scheduled walk the compiler reaches it without spilling a vector register.
+#ifndef ORION_SHADE_WAVES
+#define ORION_SHADE_WAVES 7
+#endif
 template <bool FIRST, bool SOLID>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 7)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORION_SHADE_WAVES, ORION_SHADE_WAVES)))
 void k_shade_wave_brdf(SceneView S, FrameParams F, uint32_t depth, Queues qin, const unsigned long long* __restrict__ n_live,
                        const HitRec* __restrict__ hits, Queues qout, unsigned long long* __restrict__ out_count, float4* __restrict__ rad,
                        const float2* __restrict__ jitter) {
-    shade_block<MODE_WAVE, false, MODE_WAVE, FIRST, SOLID>(S, F, depth, qin, n_live, hits, qout, out_count, rad, jitter);
+    shade_block<MODE_WAVE, false, MODE_WAVE, FIRST, SOLID, true>(S, F, depth, qin, n_live, hits, qout, out_count, rad, jitter);
 }
 
 // The last bounces of a batch, one PATH per wave.  Once a few thousand rays are left, a bounce's
