@@ -306,7 +306,8 @@ def main():
                 out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
                                "per_sample": rays / (W * H * 128),
                                "Mrays_per_s_per_gpu": rays / (W * H * 128) * value / world / 1e6,
-                               "note": "closest-hit queries per pixel-sample (profiled pass) x the timed region's samples/s per GPU"}
+                               "note": "closest-hit queries per pixel-sample (profiled pass) x the timed region's samples/s per GPU; "
+                                       "a light-sample query whose shading term is surely zero is answered without a walk and still counted"}
         if world == 1 and not args.no_ray_batches:      # (single-GPU figures: the other ranks would only wait for them)
             out["ray_batches"] = ray_batches(api)
         if world == 1 and not args.no_cpu_baseline:
