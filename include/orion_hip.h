@@ -197,6 +197,10 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *   "overlap_below" a render call of several batches starts the next batch on a second
  *                 stream (with queues of its own) once the current batch has fewer rays
  *                 than this left (default 128 Mi; 0 = one batch at a time, half the memory)
+ *   "queue_parts" 16 (default), 8, 4, 2 or 1: a render batch's ray and vertex queues come in this many partitions, each
+ *                 with a counter of its own (appends through one counter are served 11 ns apart, whatever the
+ *                 kernels do); the image does not depend on it.  Scenes whose bounce rays are drawn from the queue
+ *                 by resident waves ("draw_rays") keep one partition
  *   "draw_rays"   1 (default): on scenes that walk the 4-wide tree, the closest hits of bounce rays are found
  *                 by waves that draw rays from the queue as their lanes finish; 0: four rays per thread
  *   "wave_ahead"  1: the wave-synchronous walk of a large scene's camera rays asks for the next node and the next

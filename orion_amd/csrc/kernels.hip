@@ -117,6 +117,7 @@ struct OrionScene {
     std::string wide_why_not;         // why the scene has no wide tree ("" if it has one)
     uint32_t tail_paths = 1u << 16;   // hand a batch's last paths to k_tail once this few are left
     uint64_t batch_paths = 256u << 20;    // paths in flight per batch (128 B of queues each; less where the device's free memory asks for it)
+    uint32_t queue_parts_log2 = kPartsLog2;   // partitions of a render batch's queues (2^n; FrameParams::part_log2)
     uint32_t overlap_below = 128u << 20;   // start the next batch on the other lane once this few rays are left (0: never)
     uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
     uint64_t queue_budget = 0;            // bytes the render queues may take (0: three quarters of the device's free memory)
@@ -745,6 +746,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
         s->overlap_below = (uint32_t)value;
         return 0;
     }
+    if (!std::strcmp(name, "queue_parts")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return fail(1, "set_option: queue_parts must be 1, 2, 4, 8 or 16");
+        s->queue_parts_log2 = value == 1 ? 0u : value == 2 ? 1u : value == 4 ? 2u : value == 8 ? 3u : 4u;
+        return 0;
+    }
     if (!std::strcmp(name, "draw_rays")) {
         if (value < 0 || value > 1) return fail(1, "set_option: draw_rays must be 0 or 1");
         s->draw_rays = value != 0;
@@ -962,7 +968,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             // queue as one array and keep one partition.
             const uint32_t tile0 = B.bound >= kNarrowBelow ? kTileWide : kBlock;   // (bounce() picks the tile the same way)
             const uint32_t blocks0 = (B.bound + tile0 - 1) / tile0;
-            B.F.part_log2 = draw_rays ? 0u : kPartsLog2;
+            B.F.part_log2 = draw_rays ? 0u : s->queue_parts_log2;
             B.F.part_stride = ((blocks0 + (1u << B.F.part_log2) - 1) >> B.F.part_log2) * tile0;
             B.pbound = B.F.part_stride;
         }

@@ -638,6 +638,32 @@ def test_batching_and_repetition_change_nothing(gpu):
 
 
 @pytest.mark.gpu
+def test_queue_partitions_change_nothing(gpu):
+    """A batch's queues come in partitions with counters of their own (option queue_parts); a path's arithmetic does
+    not depend on where its records lie, so the image must keep its bits for any number of partitions: frames of
+    many tiles per partition, of fewer first-bounce blocks than partitions (some partitions stay empty), several
+    batches on two lanes, the one-path-per-wave tail on and off, BRDF and point lights."""
+    sc = gpu.Scene(conftest.load_model("cornell"), device=0)
+    eye, look, up, yv = CORNELL_CAM
+    lights = np.array([[0, 1.5, 1.0, 100 / 255, 100 / 255, 100 / 255, 32]], np.float32)
+    for W, H, spp in ((640, 360, 16), (24, 16, 5), (7, 3, 2)):
+        cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+        sc.set_option("queue_parts", 1); sc.set_option("batch_paths", 256 << 20); sc.set_option("tail_paths", 65536)
+        ref = sc.render(cam, W, H, 0, spp, 2, 60, seed=7).copy()
+        pref = sc.render(cam, W, H, 0, spp, 1, 6, seed=7, lights=lights).copy()
+        assert ref[:, :, :3].max() > 0
+        for parts in (2, 16):
+            sc.set_option("queue_parts", parts)
+            for batch, tail in ((256 << 20, 65536), (max(1, spp // 3) * W * H, 0)):
+                sc.set_option("batch_paths", batch); sc.set_option("tail_paths", tail)
+                assert np.array_equal(bits(ref), bits(sc.render(cam, W, H, 0, spp, 2, 60, seed=7))), (W, parts, batch)
+                assert np.array_equal(bits(pref), bits(sc.render(cam, W, H, 0, spp, 1, 6, seed=7, lights=lights))), (W, parts, batch)
+    with pytest.raises(gpu.OrionError):
+        sc.set_option("queue_parts", 3)
+    sc.close()
+
+
+@pytest.mark.gpu
 def test_two_lanes_change_nothing(gpu):
     """Consecutive batches alternate between two streams and overlap (option overlap_below: the next
     batch starts once the current one has that few rays left).  Whether and when they overlap must
