@@ -200,7 +200,7 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *   "queue_parts" 16 (default), 8, 4, 2 or 1: a render batch's ray and vertex queues come in this many partitions, each
  *                 with a counter of its own (appends through one counter are served 11 ns apart, whatever the
  *                 kernels do); the image does not depend on it.  Scenes whose bounce rays are drawn from the queue
- *                 by resident waves ("draw_rays") keep one partition
+ *                 by resident waves ("draw_rays") and frames without bounces keep one partition
  *   "draw_rays"   1 (default): on scenes that walk the 4-wide tree, the closest hits of bounce rays are found
  *                 by waves that draw rays from the queue as their lanes finish; 0: four rays per thread
  *   "wave_ahead"  1: the wave-synchronous walk of a large scene's camera rays asks for the next node and the next

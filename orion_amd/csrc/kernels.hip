@@ -968,7 +968,9 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             // queue as one array and keep one partition.
             const uint32_t tile0 = B.bound >= kNarrowBelow ? kTileWide : kBlock;   // (bounce() picks the tile the same way)
             const uint32_t blocks0 = (B.bound + tile0 - 1) / tile0;
-            B.F.part_log2 = draw_rays ? 0u : s->queue_parts_log2;
+            // ... and so do frames without bounces (max_depth 0), whose only appends are the first launch's, one per tile of
+            // 1024 paths: partitions buy them nothing (a 4K frame of a 200-triangle scene ran 2.8 % slower with sixteen).
+            B.F.part_log2 = (draw_rays || p->max_depth == 0) ? 0u : s->queue_parts_log2;
             B.F.part_stride = ((blocks0 + (1u << B.F.part_log2) - 1) >> B.F.part_log2) * tile0;
             B.pbound = B.F.part_stride;
         }
