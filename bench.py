@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
     ap.add_argument("--tail-paths", type=int, default=-1, help="override the library's tail hand-over threshold (A/B runs)")
     ap.add_argument("--overlap-below", type=int, default=-1, help="override the library's two-lane overlap threshold (A/B runs; 0 = one lane)")
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="scene option for A/B runs (orion_hip_scene_set_option)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (per-kernel HIP-event timings, roofline)")
     ap.add_argument("--no-ray-batches", action="store_true")
@@ -186,6 +187,9 @@ def main():
         scene.set_option("tail_paths", args.tail_paths)
     if args.overlap_below >= 0:
         scene.set_option("overlap_below", args.overlap_below)
+    for kv in args.set:
+        name, value = kv.split("=")
+        scene.set_option(name, int(value))
     if args.share_device and world > 1:     # rehearsal: the ranks share one GPU's memory
         scene.set_option("batch_paths", max(1 << 22, (64 << 20) // world))
         scene.set_option("overlap_below", 4 << 20)
