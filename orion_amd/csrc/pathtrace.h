@@ -610,7 +610,8 @@ constexpr uint32_t kMaxBins = 64;
 
 // Closest hit of every queued ray (orion/model.hpp:52-62).  Rays that miss end here: a miss
 // contributes nothing (orion/raytracer.cpp:113-114).  Rays that hit leave as complete path-vertex
-// records (origin, direction, throughput, ids + hit), compacted into `qout`/`hits`, and inside
+// records (origin, direction, throughput, ids + hit; the first bounce: path id + hit, from which the
+// shade launch computes the rest again), compacted into the block's partition of `qout`/`hits`, and inside
 // each block's tile of kTile rays they are grouped by the triangle they hit (a counting sort
 // through LDS).  The shade kernel that consumes them therefore runs on waves whose vertices lie
 // on the same surface: its light-sample rays start on one plane and aim at one light, so the
