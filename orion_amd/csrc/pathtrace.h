@@ -1057,7 +1057,18 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams F, const float4*
     float4 acc = accum[(size_t)py * F.width + px];
     const size_t first = (size_t)p * F.n_samples;
     uint32_t k = 0;
-    for (; k + 8 <= F.n_samples; k += 8) {   // eight samples at a time: their loads are under way together
+    for (; k + 16 <= F.n_samples; k += 16) {   // sixteen samples at a time: their loads are under way together
+        const size_t i = first + k;
+        const uint32_t sh = (uint32_t)(i & 31u);
+        const uint32_t w0 = hit_mask[i >> 5], w1 = sh > 16u ? hit_mask[(i >> 5) + 1] : 0u;
+        const uint32_t bits = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> sh) & 0xFFFFu;
+        float4 c[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { c[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); if (bits >> j & 1u) c[j] = rad[i + j]; }
+#pragma unroll
+        for (int j = 0; j < 16; j++) { acc.x += c[j].x; acc.y += c[j].y; acc.z += c[j].z; acc.w += 1.0f; }
+    }
+    for (; k + 8 <= F.n_samples; k += 8) {   // ... then eight
         const size_t i = first + k;
         const uint32_t sh = (uint32_t)(i & 31u);
         const uint32_t w0 = hit_mask[i >> 5], w1 = sh > 24u ? hit_mask[(i >> 5) + 1] : 0u;
