@@ -238,6 +238,38 @@ def test_render_textured_scene_matches_oracle(gpu):
     sc.close()
 
 
+@pytest.mark.gpu
+def test_render_textured_brdf_scene_matches_oracle(gpu):
+    """The emissive-light path tracer on a Cornell box with image maps on two of its meshes (the shade kernel's general
+    form: colours through the texture table, light samples whose term is surely zero still left out), and the same
+    box with a light whose vertex normals differ (no sample is left out, the light's normal is interpolated at the hit)."""
+    import copy
+    from oracle import bindings as ob
+    from orion_amd import host
+    eye, look, up, yv = CORNELL_CAM
+    W, H = 96, 54
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    rng = np.random.default_rng(12)
+    for bend_light in (False, True):
+        model = copy.deepcopy(conftest.load_model("cornell"))
+        for k in (0, 2):   # floor and back wall
+            m = model.meshes[k]
+            m.vertices = m.vertices.copy()
+            m.vertices[:, 6:8] = (m.vertices[:, 0:2] * 0.9 + 0.2).astype(np.float32)
+            model.materials[m.material].tex_diffuse = host.Texture(rng.integers(40, 256, (32, 16, 3)).astype(np.uint8))
+        if bend_light:
+            light = [m for m in model.meshes if np.any(model.materials[m.material].emissive != 0)][0]
+            light.vertices = light.vertices.copy()
+            light.vertices[0, 3:6] = np.array([0.3, -0.9, 0.1], np.float32)
+        sc = gpu.Scene(model, device=0)
+        orc = ob.OracleScene(model)
+        img = sc.render(cam, W, H, 0, 6, 2, 5, seed=13)
+        ref = orc.render(cam, W, H, 0, 6, 2, 5, seed=13, accum_mode=1)
+        assert img[:, :, :3].max() > 0
+        assert psnr(img[:, :, :3], ref[:, :, :3]) > 60.0, bend_light
+        sc.close()
+
+
 def test_render_shards_compose_exactly(gpu):
     """Sample ranges and tiles add up to the full frame bit for bit (the multi-GPU decomposition),
     whatever the batch size; device accumulators behave like host ones."""
