@@ -115,7 +115,7 @@ struct OrionScene {
     // options
     int traversal = 0;                // 0 auto, 1 lane, 2 wave, 3 one ray per wave at a time, 4 wide tree
     std::string wide_why_not;         // why the scene has no wide tree ("" if it has one)
-    uint32_t tail_paths = 1u << 16;   // hand a batch's last paths to k_tail once this few are left
+    uint32_t tail_paths = 1u << 14;   // hand a batch's last paths to k_tail once this few are left
     uint64_t batch_paths = 256u << 20;    // paths in flight per batch (128 B of queues each; less where the device's free memory asks for it)
     uint32_t queue_parts_log2 = kPartsLog2;   // partitions of a render batch's queues (2^n; FrameParams::part_log2)
     uint32_t overlap_below = 128u << 20;   // start the next batch on the other lane once this few rays are left (0: never)
