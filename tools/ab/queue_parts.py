@@ -1,8 +1,19 @@
-import os, sys, time, torch
-sys.path.insert(0, '/root/repo')
-from orion_amd import api
+#!/usr/bin/env python3
+"""What queue partitions (option queue_parts) are worth on the configured frames other than the headline's: 256-spp
+frames with 1 and 16 partitions, bounce rays drawn by resident waves (draw_rays 1: one partition whatever the option
+says) and four per thread (draw_rays 0).  Usage: python tools/ab/queue_parts.py"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from orion_amd import api  # noqa: E402
+
 for name in ("c3b_nanosuit_bounce_fhd", "c4_hindu_4k", "c2_view_test_fhd"):
-    fr = api.load_frame(os.path.join('/root/repo', "configs", name + ".rtc"), load_textures=True)
+    fr = api.load_frame(os.path.join(ROOT, "configs", name + ".rtc"), load_textures=True)
     W, H = fr.rtc.xres, fr.rtc.yres
     sc = api.Scene(fr.model, device=0)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
