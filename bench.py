@@ -9,7 +9,7 @@ The sum runs asynchronously while the next frame renders into a second accumulat
 when every sum has finished.  ms_per_step is therefore the frame's wall time, value = pixel-samples/s over
 all ranks.
 
-    python bench.py --gpus 1 --steps 4 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
@@ -144,8 +144,8 @@ def ray_batches(api, log2_rays=20, log2_large=22):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)     # (20 frames: a timed region of about 8 s on one GPU)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=FULL_SPP, help="samples per pixel of a frame (one step); the headline is 2048")
     ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
     ap.add_argument("--tail-paths", type=int, default=-1, help="override the library's tail hand-over threshold (A/B runs)")
