@@ -71,6 +71,7 @@ def oracle_lib():
         L.wide_model_create.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p]
         L.wide_model_destroy.argtypes = [C.c_void_p]
         L.wide_model_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wide_model_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.wide_model_closest_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _oracle = L
     return _oracle
@@ -221,13 +222,20 @@ class WideModel:
             oracle_lib().wide_model_destroy(self.h)
             self.h = None
 
+    def nodes(self):
+        """(n_nodes x 20 words as uploaded, n_nodes x 4 triangle counts below each slot)."""
+        words = np.zeros((self.n_nodes, 20), np.uint32); below = np.zeros((self.n_nodes, 4), np.uint32)
+        oracle_lib().wide_model_nodes(C.c_void_p(self.h), _p(words), _p(below))
+        return words, below
+
     def closest_hit(self, org, dir, cull=True, threads=1, kappa=0.0):
         o, d = _rays(org, dir)
         n = len(o)
-        ids = np.zeros((n, 2), np.uint32); tuv = np.zeros((n, 3), np.float32); st = np.zeros(105, np.float64)
-        oracle_lib().wide_model_closest_hit(self.h, _p(o), _p(d), n, 1 if cull else 0, kappa, _p(ids), _p(tuv), _p(st), threads)
+        ids = np.zeros((n, 2), np.uint32); tuv = np.zeros((n, 3), np.float32); st = np.zeros(108, np.float64)
+        oracle_lib().wide_model_closest_hit(self.h, _p(o), _p(d), n, int(cull), kappa, _p(ids), _p(tuv), _p(st), threads)
         out = dict(zip(self.STATS, st[:9].tolist()))
         out["depth_hist"] = st[9:41].copy(); out["steps_hist"] = st[41:105].copy()
+        out["danger_visits"], out["danger_slots"], out["slots_seen"] = st[105:108].tolist()
         return ids, tuv, out
 
 

@@ -43,10 +43,11 @@ struct Model {
     std::vector<Tri> tris;
     std::vector<uint32_t> tri_mesh, mesh_base;
     orion_wide::WideTree tree;
+    std::vector<std::vector<uint32_t>> below;   // 4 per wide node: triangle slots below (mode 3, the ideal certificate; built on first use)
 };
 
 struct Stats {
-    uint64_t nodes = 0, own_fail = 0, leaves = 0, tris = 0, stale = 0, candidates = 0;
+    uint64_t nodes = 0, own_fail = 0, leaves = 0, tris = 0, stale = 0, candidates = 0, danger_visits = 0, danger_slots = 0, slots_seen = 0;
     uint32_t max_stack = 0;
     double max_excess = 0.0;   // in units of the scene's pad
     uint64_t untame = 0;
@@ -82,13 +83,35 @@ inline bool tame(const Model& M, V3 o, V3 d) {
 
 // cull = false: every slot the reference's rule allows is visited (the decoded boxes are ignored), which is
 // the reference's candidate set; used to measure the excess.  Returns false for a ray the walk does not take.
-bool walk(const Model& M, V3 o, V3 d, bool cull, float kappa, Best& best, Stats& st) {
+// The guard of the product's walk (orion_amd/csrc/wide_walk.h: wide_guard_of, wide_danger): the direction as signed
+// bytes of length 127, a slot's cone word (wide_bvh.h: guard_word), "dangerous" iff |A . D| < 127 c.
+struct GuardDir { int x, y, z; bool on; };
+inline GuardDir guard_dir(const Model& M, V3 d) {
+    GuardDir g = {0, 0, 0, false};
+    const float l2 = fmaf(d.x, d.x, fmaf(d.y, d.y, d.z * d.z));
+    if (!(l2 * 1.00001f <= M.tree.guard_dlen * M.tree.guard_dlen)) {
+        const float r = 127.0f * (1.0f / std::sqrt(l2));
+        auto q = [&](float v) { const int i = (int)std::lrintf(v * r); return std::max(-127, std::min(127, i)); };
+        g.x = q(d.x); g.y = q(d.y); g.z = q(d.z); g.on = true;
+    }
+    return g;
+}
+inline bool guard_danger(uint32_t word, const GuardDir& g) {
+    if (!g.on) return false;
+    const int ax = (int8_t)(word & 0xFFu), ay = (int8_t)((word >> 8) & 0xFFu), az = (int8_t)((word >> 16) & 0xFFu), c = (int8_t)(word >> 24);
+    const int dot = ax * g.x + ay * g.y + az * g.z;
+    return std::max(dot - 127 * c, -dot - 127 * c) < 0;
+}
+
+bool walk(const Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& st) {
     if (!tame(M, o, d)) { st.untame++; return false; }
     const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float pad = M.tree.pad;
     best.t = std::numeric_limits<float>::infinity(); best.u = best.v = 0.0f; best.slot = 0xFFFFFFFFu;
-    struct Entry { uint32_t ref; float tmin; };
+    struct Entry { uint32_t ref; float tmin; bool danger; float cull_t; };
     std::vector<Entry> stack;
+    const GuardDir gd = guard_dir(M, d);
+    const double dlen = std::sqrt((double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z);
     uint32_t cur = 0;           // node index, or 0x80000000 | count << 25 | first triangle slot
     uint32_t my_depth = 0, my_steps = 0;
     const uint32_t kDone = 0x7FFFFFFFu;
@@ -118,8 +141,27 @@ bool walk(const Model& M, V3 o, V3 d, bool cull, float kappa, Best& best, Stats&
                     }
                     float a, b;
                     slab(lo, hi, o, inv, a, b);
-                    if (cull && !((b >= a) && (b >= 0.0f) && (a <= best.t))) continue;
-                    hit[nh].ref = refs[k]; hit[nh].tmin = a; nh++;
+                    const bool met = (b >= a) && (b >= 0.0f);
+                    const bool within = met && (a <= best.t);
+                    bool danger = false;
+                    st.slots_seen++;
+                    if (cull == 2) danger = guard_danger(n.guard[k], gd);
+                    if (cull == 3) {   // the ideal certificate: is any triangle below ill conditioned for this ray and large enough to be accepted?
+                        for (uint32_t s : M.below[4 * cur + k]) {
+                            const Tri& T = M.tris[s];
+                            const double e1[3] = {T.e1[0], T.e1[1], T.e1[2]}, e2[3] = {T.e2[0], T.e2[1], T.e2[2]};
+                            const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                            const double m = std::sqrt((e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) * (e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]));
+                            if (dlen * m <= (double)orion_dev::kGuardHarmless) continue;
+                            if (std::fabs(c[0] * d.x + c[1] * d.y + c[2] * d.z) < (double)orion_dev::kGuardKappa * dlen * m) { danger = true; break; }
+                        }
+                    }
+                    // a dangerous inner slot the ray's line misses fails the reference's own box test; a dangerous leaf is visited anyway
+                    if (danger && !(refs[k] & 0x80000000u) && !met) danger = false;
+                    if (danger && !within) st.danger_slots++;
+                    const float cull_t = danger ? -1.0f : a;
+                    if (cull && !within && !danger) continue;
+                    hit[nh].ref = refs[k]; hit[nh].tmin = (within ? a : 3.0e38f); hit[nh].danger = danger; hit[nh].cull_t = cull_t; nh++;
                 }
             }
             // the nearest slot next; the others wait on the stack in slot order
@@ -129,7 +171,7 @@ bool walk(const Model& M, V3 o, V3 d, bool cull, float kappa, Best& best, Stats&
             for (int i = nh - 1; i >= 1; i--) stack.push_back(hit[i]);
             st.max_stack = std::max<uint32_t>(st.max_stack, (uint32_t)stack.size());
             my_depth = std::max<uint32_t>(my_depth, (uint32_t)stack.size());
-            if (nh) { cur = hit[0].ref; continue; }
+            if (nh) { if (hit[0].tmin > best.t) st.danger_visits++; cur = hit[0].ref; continue; }
         } else {
             const uint32_t first = cur & 0x1FFFFFFu, count = (cur >> 25) & 63u;
             st.leaves++; my_steps++;
@@ -162,13 +204,31 @@ bool walk(const Model& M, V3 o, V3 d, bool cull, float kappa, Best& best, Stats&
         cur = kDone;
         while (!stack.empty()) {
             const Entry e = stack.back(); stack.pop_back();
-            if (cull && e.tmin > best.t) { st.stale++; continue; }
+            if (cull && e.cull_t > best.t) { st.stale++; continue; }
+            if (e.tmin > best.t) st.danger_visits++;
             cur = e.ref; break;
         }
     }
     st.depth_hist[std::min<uint32_t>(my_depth, 31)]++;
     st.steps_hist[std::min<uint32_t>(my_steps / 4, 63)]++;
     return true;
+}
+
+// triangles below a reference
+void collect(const Model& M, uint32_t ref, std::vector<uint32_t>& out) {
+    if (ref == orion_dev::kWideEmpty) return;
+    if (ref & 0x80000000u) { const uint32_t first = ref & 0x1FFFFFFu, count = (ref >> 25) & 63u; for (uint32_t s = first; s < first + count; s++) out.push_back(s); return; }
+    const WideNode& n = M.tree.nodes[ref];
+    collect(M, n.ref0, out); collect(M, n.ref1, out); collect(M, n.ref2, out); collect(M, n.ref3, out);
+}
+
+void build_below(Model& M) {
+    M.below.assign(4 * M.tree.nodes.size(), {});
+    for (size_t i = 0; i < M.tree.nodes.size(); i++) {
+        const WideNode& n = M.tree.nodes[i];
+        const uint32_t refs[4] = {n.ref0, n.ref1, n.ref2, n.ref3};
+        for (int k = 0; k < 4; k++) collect(M, refs[k], M.below[4 * i + k]);
+    }
 }
 
 } // namespace
@@ -217,12 +277,23 @@ void wide_model_info(void* h, uint32_t* info, float* finfo) {
     finfo[0] = M->tree.pad; finfo[1] = M->tree.org_bound;
 }
 
+// The tree's nodes as they are uploaded (n_nodes x 20 words), and per node and slot the number of triangles below.
+void wide_model_nodes(void* h, uint32_t* words, uint32_t* below4) {
+    Model* M = static_cast<Model*>(h);
+    std::memcpy(words, M->tree.nodes.data(), M->tree.nodes.size() * sizeof(WideNode));
+    if (below4) {
+        if (M->below.empty()) build_below(*M);
+        for (size_t i = 0; i < M->below.size(); i++) below4[i] = (uint32_t)M->below[i].size();
+    }
+}
+
 // ids: n x 2 (mesh, triangle; 0xFFFFFFFF = miss, 0xFFFFFFFE = ray not taken by the walk), tuv: n x 3.
 // stats (doubles): nodes, own-box failures, leaves, triangle tests, stale pops, candidates, deepest stack,
 // largest excess (in pads), rays not taken.
 void wide_model_closest_hit(void* h, const float* org, const float* dir, uint32_t n, int cull, float kappa, uint32_t* ids, float* tuv,
                             double* stats, int threads) {
-    const Model* M = static_cast<Model*>(h);
+    Model* M = static_cast<Model*>(h);
+    if (cull == 3 && M->below.empty()) build_below(*M);
     Stats total;
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
     {
@@ -231,7 +302,7 @@ void wide_model_closest_hit(void* h, const float* org, const float* dir, uint32_
         for (int64_t i = 0; i < (int64_t)n; i++) {
             const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
             Best b;
-            if (!walk(*M, o, d, cull != 0, kappa, b, st)) { ids[2 * i] = ids[2 * i + 1] = 0xFFFFFFFEu; tuv[3 * i] = tuv[3 * i + 1] = tuv[3 * i + 2] = 0.0f; continue; }
+            if (!walk(*M, o, d, cull, kappa, b, st)) { ids[2 * i] = ids[2 * i + 1] = 0xFFFFFFFEu; tuv[3 * i] = tuv[3 * i + 1] = tuv[3 * i + 2] = 0.0f; continue; }
             if (b.slot == 0xFFFFFFFFu) { ids[2 * i] = ids[2 * i + 1] = 0xFFFFFFFFu; }
             else { const uint32_t g = M->tris[b.slot].gtri, mi = M->tri_mesh[b.slot]; ids[2 * i] = mi; ids[2 * i + 1] = g - M->mesh_base[mi]; }
             tuv[3 * i] = b.t; tuv[3 * i + 1] = b.u; tuv[3 * i + 2] = b.v;
@@ -239,7 +310,7 @@ void wide_model_closest_hit(void* h, const float* org, const float* dir, uint32_
 #pragma omp critical
         {
             total.nodes += st.nodes; total.own_fail += st.own_fail; total.leaves += st.leaves; total.tris += st.tris;
-            total.stale += st.stale; total.candidates += st.candidates; total.untame += st.untame;
+            total.stale += st.stale; total.candidates += st.candidates; total.untame += st.untame; total.danger_visits += st.danger_visits; total.danger_slots += st.danger_slots; total.slots_seen += st.slots_seen;
             total.max_stack = std::max(total.max_stack, st.max_stack);
             total.max_excess = std::max(total.max_excess, st.max_excess);
             for (int k = 0; k < 32; k++) total.depth_hist[k] += st.depth_hist[k];
@@ -252,6 +323,7 @@ void wide_model_closest_hit(void* h, const float* org, const float* dir, uint32_
         stats[8] = (double)total.untame;
         for (int k = 0; k < 32; k++) stats[9 + k] = (double)total.depth_hist[k];
         for (int k = 0; k < 64; k++) stats[41 + k] = (double)total.steps_hist[k];
+        stats[105] = (double)total.danger_visits; stats[106] = (double)total.danger_slots; stats[107] = (double)total.slots_seen;
     }
 }
 

@@ -246,8 +246,9 @@ template <bool QUICK_DIV, bool AHEAD>
 __device__ __forceinline__ void traverse_wave_closest_asm(const SceneView& S, V3 o, V3 d, V3 inv, HitRec& h, uint32_t next, uint32_t fast);
 // Large scenes: one test of the box around all the meshes' roots (the spare record behind the node array) before the
 // roots are tested one after the other.  Exact: for rays without NaN products (`fast`, wave-uniform) the slab test is
-// monotone in the box, so a ray that misses this box fails the reference's test at every root.  Camera rays that miss
-// a model of a dozen meshes are done after one box test instead of a dozen.  Smaller scenes are walked from inside
+// monotone in the box, so a ray that misses this box fails the reference's test at every root.  (A root that is a leaf
+// has no test in the reference: a scene with one gets a record that holds all of space, orion_hip_scene_create.)  Camera
+// rays that miss a model of a dozen meshes are done after one box test instead of a dozen.  Smaller scenes are walked from inside
 // (nothing to skip), and there every instruction counts.
 constexpr uint32_t kSceneBoxAbove = 384;   // nodes
 __device__ __forceinline__ void scene_box_gate(const SceneView& S, V3 o, V3 inv, bool fast, bool& active, uint32_t& next) {

@@ -645,12 +645,18 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
     // One spare record behind each array: the walk that asks for the next node ahead of time (traverse_wave_ahead)
     // reads one past the node it is at.
     // The spare node record holds the box around all the meshes' roots (traverse_wave tests it first on large scenes).
+    // A mesh whose root is a leaf has no box in the reference's walk (orion/avx/sbvh.cpp:50-59: its triangles are tested
+    // whatever the ray): with such a mesh in the scene the record holds all of space, which every ray the gate sees meets.
     {
         Node all{};
         for (int a = 0; a < 3; a++) { all.lo[a] = INFINITY; all.hi[a] = -INFINITY; }
+        bool leaf_root = false;
         for (const std::vector<uint32_t>& w : node_where)
-            if (!w.empty() && w[0] != kInvalid)
+            if (!w.empty() && w[0] != kInvalid) {
+                leaf_root = leaf_root || (nodes[w[0]].b & kLeafFlag) != 0u;
                 for (int a = 0; a < 3; a++) { all.lo[a] = std::fmin(all.lo[a], nodes[w[0]].lo[a]); all.hi[a] = std::fmax(all.hi[a], nodes[w[0]].hi[a]); }
+            }
+        if (leaf_root) for (int a = 0; a < 3; a++) { all.lo[a] = -INFINITY; all.hi[a] = INFINITY; }
         nodes.push_back(all);
     }
     if ((rc = upload(s, nodes, &v.nodes))) return bail(rc);
@@ -675,6 +681,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         if ((rc = upload(s, wide_bin, &v.wide_bin))) return bail(rc);
         if ((rc = upload(s, wide.nodes, &v.wide))) return bail(rc);
         v.n_wide = (uint32_t)wide.nodes.size(); v.wide_pad = wide.pad; v.wide_grow0 = wide.pad * (1.0f + 2.0f * kWideSlack); v.wide_org_bound = wide.org_bound;
+        v.wide_guard = 1u; v.wide_guard_dlen = wide.guard_dlen;
     }
     s->wide_why_not = wide.why_not;
     {   // |det| = |e1 . (d x e2)| <= 6 D E^2 for direction components up to D and edge components up to E;
@@ -734,6 +741,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
         if (value == 4 && s->view.n_wide == 0) return fail(1, "set_option: the scene has no wide tree (" + s->wide_why_not + ")");
         if (value == 3 && s->view.n_items == 0) return fail(1, "set_option: the scene is too large for one ray per wave (more than 64 inner nodes + triangles)");
         s->traversal = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "wide_guard")) {
+        if (value < 0 || value > 1) return fail(1, "set_option: wide_guard must be 0 or 1");
+        s->view.wide_guard = (uint32_t)value;
         return 0;
     }
     if (!std::strcmp(name, "tail_paths")) {

@@ -363,6 +363,7 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
     HitRec h = miss_rec();
     WideState w; w.cur = kWideEmpty; w.sp = 0u; w.best_slot = 0u;
     bool quick_det = false, slow = false;
+    WideGuard guard_words; guard_words.dp = 0u; guard_words.dm = 0u;
     // Sharing (see wide_share): the lane whose ray this lane walks a part of, and how many lanes walk parts of this lane's.
     uint32_t owner = kNoOwner, lent = 0u;
 #if ORION_WIDE_STATS
@@ -413,7 +414,7 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
                     inv = ray_inverse_quick(d);
                     h = miss_rec();
                     ray = i;
-                    if (wide_tame(S, o, d)) { w.cur = 0u; w.sp = 0u; w.best_slot = 0u; }
+                    if (wide_tame(S, o, d)) { w.cur = 0u; w.sp = 0u; w.best_slot = 0u; guard_words = wide_guard_of(S, d); }
                     else slow = true;
                 }
                 g_next = min(g_end, g_next + (uint32_t)__popcll(mi));
@@ -421,7 +422,11 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
         }
         bool sharing = false;   // (wave-uniform) lanes are free to take parts of other lanes' rays
 #if ORION_WIDE_SHARE
-        if (pool_empty) sharing = wide_share(w, o, d, inv, h, quick_det, slow, idle, owner, lent);
+        if (pool_empty) {
+            const bool had = w.cur != kWideEmpty;
+            sharing = wide_share(w, o, d, inv, h, quick_det, slow, idle, owner, lent);
+            if (!had && w.cur != kWideEmpty) guard_words = wide_guard_of(S, d);   // a part of another lane's ray: its direction
+        }
 #endif
         if (sharing) WIDE_STAT(9, 1u);
         if (__ballot(w.cur != kWideEmpty || slow) == 0ull) {
@@ -438,13 +443,14 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
         }
         // Node steps until nobody is at a node -- or until enough lanes wait at a leaf, or enough have run
         // out of work to make fetching worthwhile: they would sit idle while the others walk on.
+        const bool guard = __any(w.cur != kWideEmpty && guard_words.dp != 0u);
         for (;;) {
             const bool at_node = wide_at_node(w);
             if (!__any(at_node)) break;
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kLeafQuorumWide) break;
             if (!pool_empty && (uint32_t)__popcll(__ballot(w.cur == kWideEmpty && !slow)) >= kRefillMin) break;
             WIDE_STAT(1, 1u); WIDE_STAT(2, (uint32_t)__popcll(__ballot(at_node)));
-            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid);
+            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, guard_words, guard);
             if (__any(over)) {   // a stack that is full: that node's subtree goes to the unculled walk
                 if (over && !wide_overflow<ANY>(S, o, d, inv, false, h, w, tid)) slow = true;
             }

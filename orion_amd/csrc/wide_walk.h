@@ -97,15 +97,64 @@ __device__ __forceinline__ float wide_slot(const WideBytes& q, V3 c, V3 l, V3 u,
     return hit ? tmin : __builtin_inff();   // (a negative tmin orders the slots that hold the origin)
 }
 
+// The guard (see the header comment): the ray's direction as two words of signed bytes, D = d^ * 127 rounded, in the
+// forms (Dx, Dy, Dz, -127) and (-Dx, -Dy, -Dz, -127).  A slot's guard word is (Ax, Ay, Az, c) (wide_bvh.h: guard_word), so the two
+// byte-wise dot products are A . D - 127 c and -(A . D) - 127 c: both negative iff |A . D| < 127 c, the slot may then
+// hold a triangle whose test is ill conditioned for this ray.  Both words zero: the guard is off for the ray.
+struct WideGuard { uint32_t dp, dm; };
+
+__device__ __forceinline__ WideGuard wide_guard_of(const SceneView& S, V3 d) {
+    WideGuard g; g.dp = 0u; g.dm = 0u;
+    const float l2 = fmaf(d.x, d.x, fmaf(d.y, d.y, d.z * d.z));
+    // Rays no longer than wide_guard_dlen (with room for this sum's rounding) cannot be accepted by an ill-conditioned test
+    // (device_types.h: kGuardHarmless).  Tame directions (wide_tame) have components between 2^-40 and 2^40: l2 is a normal number.
+    if (S.wide_guard != 0u && !(l2 * 1.00001f <= S.wide_guard_dlen * S.wide_guard_dlen)) {
+        const float r = 127.0f * __frsqrt_rn(l2);
+        const int x = __float2int_rn(d.x * r), y = __float2int_rn(d.y * r), z = __float2int_rn(d.z * r);   // (|.| <= 127 up to the rounding of r: clamped)
+        const int cx = max(-127, min(127, x)), cy = max(-127, min(127, y)), cz = max(-127, min(127, z));
+        g.dp = (uint32_t)(cx & 0xFF) | (uint32_t)(cy & 0xFF) << 8 | (uint32_t)(cz & 0xFF) << 16 | 0x81000000u;
+        g.dm = (uint32_t)(-cx & 0xFF) | (uint32_t)(-cy & 0xFF) << 8 | (uint32_t)(-cz & 0xFF) << 16 | 0x81000000u;
+    }
+    return g;
+}
+
+__device__ __forceinline__ bool wide_danger(uint32_t word, WideGuard g) {
+    const int a = __builtin_amdgcn_sdot4((int)word, (int)g.dp, 0, false), b = __builtin_amdgcn_sdot4((int)word, (int)g.dm, 0, false);
+    return max(a, b) < 0;
+}
+
+// Slot K with the guard: `vis` = the slot is to be visited, `keep` = it may not be dropped later however near the best hit
+// has come by then (it goes onto the stack with distance 0).  A slot that is not dangerous is skipped as in wide_slot.  A
+// dangerous inner slot is visited iff the ray meets its grown box at all, however far away (if it does not, the
+// reference's own test of the inner node's box fails too); a dangerous leaf is visited whatever its box says, as in the
+// reference.  Slots visited only because they are dangerous come after the others (distance kWideLast).
+constexpr float kWideLast = 3.0e38f;
+template <int K>
+__device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 l, V3 u, float best, uint32_t ref, uint32_t word, WideGuard g, bool& keep) {
+    const float t1x = fmaf(byte_of<K>(q.nx), c.x, l.x), t2x = fmaf(byte_of<K>(q.fx), c.x, u.x);
+    const float t1y = fmaf(byte_of<K>(q.ny), c.y, l.y), t2y = fmaf(byte_of<K>(q.fy), c.y, u.y);
+    const float t1z = fmaf(byte_of<K>(q.nz), c.z, l.z), t2z = fmaf(byte_of<K>(q.fz), c.z, u.z);
+    const float tmin = vmax3(t1x, t1y, t1z);
+    const float tmax = vmin3(t2x, t2y, t2z);
+    const bool met = vmax(tmin, 0.0f) <= tmax;            // the ray meets the grown box somewhere
+    const bool within = met & (tmin <= best);
+    const bool danger = wide_danger(word, g);
+    const bool leaf = (ref & kWideLeaf) != 0u;
+    keep = danger;
+    const bool vis = (ref != kWideEmpty) & (within | (danger & (met | leaf)));
+    return vis ? (within ? tmin : kWideLast) : __builtin_inff();
+}
+
 // One wide node: the reference's test on its own box, then the four slots; the nearest one is next and the
 // others go onto the stack.  Returns false, with the lane still at the node, if the stack would overflow
-// (wide_overflow then deals with the node's subtree).
-__device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid) {
+// (wide_overflow then deals with the node's subtree).  `guard`: wave-uniform, whether any lane's ray needs the guard.
+__device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid, WideGuard g, bool guard) {
     const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
     float4 A = np[0], B = np[1], C = np[2], D = np[3];
     pin(A); pin(B); pin(C); pin(D);
     const float inf = __builtin_inff();
     float t0 = inf, t1 = inf, t2 = inf, t3 = inf;
+    bool k0 = false, k1 = false, k2 = false, k3 = false;
     const uint32_t r0 = __float_as_uint(A.w), r1 = __float_as_uint(B.w), r2 = __float_as_uint(D.z), r3 = __float_as_uint(D.w);
     // AABB::intersect on the node's own box (orion/AABB.hpp:79-99; the form of slab_hit_fast), keeping its terms
     const V3 n0 = mk(A.x - o.x, A.y - o.y, A.z - o.z), n1 = mk(B.x - o.x, B.y - o.y, B.z - o.z);
@@ -118,21 +167,30 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
         // ten-thousandths of the slack).  g = pad + slack * (reach + 2 pad), reach = the origin's distance to the
         // farthest corner of the node's box.
         const float reach = vmax(vmax3_abs(n0.x, n1.x, n0.y), vmax3_abs(n1.y, n0.z, n1.z));
-        const float g = fmaf(kWideSlack, reach, S.wide_grow0);
+        const float gr = fmaf(kWideSlack, reach, S.wide_grow0);
         // Which of a slab's two planes the ray meets first is the sign of the direction (bytes: lower <= upper, c has the
         // sign of inv, l and u below lie on the entry and on the exit side), so the entry and exit distances are
         // picked per node, one word of four slots at a time, not compared per slot.
         const V3 c = mk((s1.x - s0.x) * kWideInvCells, (s1.y - s0.y) * kWideInvCells, (s1.z - s0.z) * kWideInvCells);
-        const V3 l = mk(fmaf(-g, fabsf(inv.x), s0.x), fmaf(-g, fabsf(inv.y), s0.y), fmaf(-g, fabsf(inv.z), s0.z));
-        const V3 u = mk(fmaf(g, fabsf(inv.x), s0.x), fmaf(g, fabsf(inv.y), s0.y), fmaf(g, fabsf(inv.z), s0.z));
+        const V3 l = mk(fmaf(-gr, fabsf(inv.x), s0.x), fmaf(-gr, fabsf(inv.y), s0.y), fmaf(-gr, fabsf(inv.z), s0.z));
+        const V3 u = mk(fmaf(gr, fabsf(inv.x), s0.x), fmaf(gr, fabsf(inv.y), s0.y), fmaf(gr, fabsf(inv.z), s0.z));
         const bool ux = inv.x > 0.0f, uy = inv.y > 0.0f, uz = inv.z > 0.0f;
         const uint32_t lx = __float_as_uint(C.x), ly = __float_as_uint(C.y), lz = __float_as_uint(C.z);
         const uint32_t hx = __float_as_uint(C.w), hy = __float_as_uint(D.x), hz = __float_as_uint(D.y);
         const WideBytes q = {ux ? lx : hx, uy ? ly : hy, uz ? lz : hz, ux ? hx : lx, uy ? hy : ly, uz ? hz : lz};
-        t0 = wide_slot<0>(q, c, l, u, best, r0);
-        t1 = wide_slot<1>(q, c, l, u, best, r1);
-        t2 = wide_slot<2>(q, c, l, u, best, r2);
-        t3 = wide_slot<3>(q, c, l, u, best, r3);
+        if (guard) {
+            float4 G = np[4];
+            pin(G);
+            t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, __float_as_uint(G.x), g, k0);
+            t1 = wide_slot_guarded<1>(q, c, l, u, best, r1, __float_as_uint(G.y), g, k1);
+            t2 = wide_slot_guarded<2>(q, c, l, u, best, r2, __float_as_uint(G.z), g, k2);
+            t3 = wide_slot_guarded<3>(q, c, l, u, best, r3, __float_as_uint(G.w), g, k3);
+        } else {
+            t0 = wide_slot<0>(q, c, l, u, best, r0);
+            t1 = wide_slot<1>(q, c, l, u, best, r1);
+            t2 = wide_slot<2>(q, c, l, u, best, r2);
+            t3 = wide_slot<3>(q, c, l, u, best, r3);
+        }
     }
     const float tn = vmin(vmin3(t0, t1, t2), t3);
     if (!(tn < inf)) { wide_pop(w, best, tid); return true; }
@@ -144,10 +202,11 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
     const uint32_t more = (p0 ? 1u : 0u) + (p1 ? 1u : 0u) + (p2 ? 1u : 0u) + (p3 ? 1u : 0u);
     if (w.sp + more > (uint32_t)kWideStack) return false;   // (w.cur still names the node: see wide_overflow)
     uint32_t sp = w.sp;
-    wide_push(sp, tid, r3, t3); sp += p3 ? 1u : 0u;
-    wide_push(sp, tid, r2, t2); sp += p2 ? 1u : 0u;
-    wide_push(sp, tid, r1, t1); sp += p1 ? 1u : 0u;
-    wide_push(sp, tid, r0, t0); sp += p0 ? 1u : 0u;
+    // (a slot that is kept goes on with distance 0: wide_pop never drops it)
+    wide_push(sp, tid, r3, k3 ? 0.0f : t3); sp += p3 ? 1u : 0u;
+    wide_push(sp, tid, r2, k2 ? 0.0f : t2); sp += p2 ? 1u : 0u;
+    wide_push(sp, tid, r1, k1 ? 0.0f : t1); sp += p1 ? 1u : 0u;
+    wide_push(sp, tid, r0, k0 ? 0.0f : t0); sp += p0 ? 1u : 0u;
     w.sp = sp;
     w.cur = e0 ? r0 : (e1 ? r1 : (e2 ? r2 : r3));
     return true;
@@ -217,6 +276,8 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
     const uint32_t tid = threadIdx.x;
     WideState w; w.cur = 0u; w.sp = 0u; w.best_slot = 0u;
     bool ok = true;
+    const WideGuard g = wide_guard_of(S, d);
+    const bool guard = __any(g.dp != 0u);
     // The lanes of the wave that walk do so together: node steps until nobody is at a node or kStaticQuorum lanes
     // wait at a leaf (they would idle while the others walk on), then the leaves (nanosuit frame with four
     // bounces: +13 % against "every lane to its next leaf first"; 8, 12 and 16 lanes within 2 % of each other).
@@ -226,7 +287,7 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
             const bool at_node = wide_at_node(w);
             if (!__any(at_node)) break;
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kStaticQuorum) break;
-            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid);
+            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, g, guard);
             if (__any(over)) {
                 if (over) ok = wide_overflow<ANY>(S, o, d, inv, false, h, w, tid) && ok;
             }

@@ -5,7 +5,7 @@ Development container only: the GPU box has neither /root/reference nor a need t
 this.  The fixtures are data (inputs + the reference's outputs); rerun after changing a
 ray generator in tests/raygen.py:
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--rays-only]
 """
 import os
 import sys
@@ -50,7 +50,14 @@ def ray_batches(name, model, ref):
     o3, d3 = raygen.rays_to_surface(o2, model, seed=3)
     o4, d4 = raygen.box_rays(model, N_RAYS, seed=4)
     o5, d5 = raygen.edge_case_rays(model)
-    return {"primary": (o1, d1), "bounce": (o2, d2), "shadow": (o3, d3), "box": (o4, d4), "edge": (o5, d5)}
+    # rays along triangle planes, and behind them the rays on which a distance-culled walk WITHOUT a guard was seen to
+    # differ from the reference's walk on the GPU (tools/ab/stress_wide.py with WIDE_GUARD=0; nanosuit: all 349 of 2^30,
+    # hindu: 2048 of 170 144)
+    o6, d6 = raygen.grazing_rays(model, 2 * N_RAYS, seed=6)
+    logged = np.load(os.path.join(HERE, "grazing_logged.npz"))
+    if f"{name}_org" in logged:
+        o6 = np.concatenate([o6, logged[f"{name}_org"]]); d6 = np.concatenate([d6, logged[f"{name}_dir"]])
+    return {"primary": (o1, d1), "bounce": (o2, d2), "shadow": (o3, d3), "box": (o4, d4), "edge": (o5, d5), "grazing": (o6, d6)}
 
 
 def main():
@@ -86,6 +93,8 @@ def main():
                 out[f"{tag}_org"], out[f"{tag}_dir"], out[f"{tag}_ids"], out[f"{tag}_tuv"] = o, d, ids, tuv
         np.savez_compressed(os.path.join(HERE, f"rays_{name}.npz"), **out)
 
+    if "--rays-only" in sys.argv:   # (the component vectors hold rsqrt results of the machine that made them)
+        return
     # ---- component vectors --------------------------------------------------------------
     comp = {}
     rng = np.random.default_rng(5)

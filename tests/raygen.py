@@ -96,6 +96,30 @@ def box_rays(model, n, seed):
     return org, (tgt - org).astype(np.float32)
 
 
+def grazing_rays(model, n, seed):
+    """Rays that run along a triangle's plane at a slope between 1e-8 and 1e-2, through a point of the triangle or just
+    beside it, from up to a few scene sizes back, direction length 0.1 to 10: where Triangle::intersect's t, u, v
+    (orion/geometry.hpp:80-136) are worst conditioned -- a determinant a few rounding errors above the 1e-6 it rejects,
+    numerators that are rounding residue."""
+    rng = np.random.default_rng(seed)
+    tris = np.concatenate([m.vertices[m.indices.reshape(-1, 3), :3] for m in model.meshes if m.n_triangles]).astype(np.float64)
+    lo = tris.reshape(-1, 3).min(0); hi = tris.reshape(-1, 3).max(0)
+    tp = tris[rng.integers(0, len(tris), n)]
+    e1 = tp[:, 1] - tp[:, 0]; e2 = tp[:, 2] - tp[:, 0]
+    nr = np.cross(e1, e2); nr /= np.maximum(np.linalg.norm(nr, axis=1, keepdims=True), 1e-30)
+    a = rng.random(n) * 1.4 - 0.2; b = rng.random(n) * 1.4 - 0.2
+    p = tp[:, 0] + a[:, None] * e1 + b[:, None] * e2
+    ang = rng.random(n) * 2 * np.pi
+    u1 = e1 / np.maximum(np.linalg.norm(e1, axis=1, keepdims=True), 1e-30); u2 = np.cross(nr, u1)
+    inplane = np.cos(ang)[:, None] * u1 + np.sin(ang)[:, None] * u2
+    slope = 10.0 ** (-8.0 + 6.0 * rng.random(n)) * (rng.integers(0, 2, n) * 2 - 1)
+    d = inplane + slope[:, None] * nr
+    back = (hi - lo).max() * 10.0 ** (-2.0 + 2.5 * rng.random(n))
+    o = p - back[:, None] * d
+    d = d * (10.0 ** (-1.0 + 2.0 * rng.random(n)))[:, None]
+    return o.astype(np.float32), d.astype(np.float32)
+
+
 def edge_case_rays(model, seed=7):
     """Rays built to land on the predicates' edges: axis-parallel directions (zero
     components -> infinite reciprocals), origins on box planes, rays through triangle

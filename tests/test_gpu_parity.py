@@ -13,8 +13,8 @@ import raygen
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell", "view_test", "hindu", "nanosuit", "soup"]
-BATCHES = ["primary", "bounce", "shadow", "box", "edge"]
-MODES = [(1, "lane"), (2, "wave"), (4, "wide")]
+BATCHES = ["primary", "bounce", "shadow", "box", "edge", "grazing"]
+MODES = [(0, "auto"), (1, "lane"), (2, "wave"), (4, "wide")]
 
 
 def set_walk(api, sc, mode):
@@ -70,6 +70,71 @@ def test_closest_hit_golden(gpu, name, mode, tag):
         assert np.array_equal(ids, g[f"{b}_ids"]), f"{name}/{b}/{tag}: ids"
         assert np.array_equal(bits(tuv), bits(g[f"{b}_tuv"])), f"{name}/{b}/{tag}: t,u,v bits"
     sc.set_option("traversal", 0)
+
+
+@pytest.mark.parametrize("name", ["nanosuit", "soup", "hindu"])
+def test_rays_along_triangle_planes(gpu, name):
+    """The grazing batch (reference-generated): rays along triangle planes, where the reference's triangle test accepts
+    rounding noise -- a determinant a few rounding errors above the 1e-6 it rejects, t, u, v that are ratios of residue, "hits"
+    up to a dozen box sizes away from the triangle.  Behind them the rays on which a distance-culled walk without a guard
+    was seen to differ from the reference's walk.  Every walk must return the reference's bits, the default one included;
+    with the guard switched off (option "wide_guard" = 0) the wide walk is known to miss some of them, which is what
+    shows that the batch tests something."""
+    g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
+    o, d = g["grazing_org"], g["grazing_dir"]
+    sc = scene_for(gpu, name)
+    for mode in (0, 1, 4):
+        sc.set_option("traversal", mode)
+        ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+        assert np.array_equal(ids, g["grazing_ids"]), f"{name}/traversal {mode}: ids"
+        assert np.array_equal(bits(tuv), bits(g["grazing_tuv"])), f"{name}/traversal {mode}: t,u,v bits"
+        occ = sc.any_hit(o, d)
+        assert np.array_equal(occ.astype(bool), g["grazing_ids"][:, 0] != gpu.INVALID), f"{name}/traversal {mode}: any hit"
+    sc.set_option("traversal", 4); sc.set_option("wide_guard", 0)
+    ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+    differ = int(((ids != g["grazing_ids"]).any(1) | (bits(tuv) != bits(g["grazing_tuv"])).any(1)).sum())
+    sc.set_option("wide_guard", 1); sc.set_option("traversal", 0)
+    if name != "soup":   # (the soup's triangles are too small for an ill-conditioned test to pass the reference's 1e-6)
+        assert differ > 0, "the unguarded walk no longer differs on the logged rays: the batch has lost its teeth"
+    else:
+        assert differ == 0
+
+
+def test_leaf_root_mesh_on_the_face_of_a_large_scene(gpu):
+    """A mesh whose tree is one leaf has no box in the reference's walk (orion/avx/sbvh.cpp:50-59): its triangles are
+    tested whatever the ray.  Large scenes test one box around all the roots before the wave-synchronous walk of coherent
+    rays; a quad lying on a face of that box must still be found by rays that touch the box in one point of the quad's
+    edge only (the slab test's strict tmax > tmin rejects those)."""
+    from orion_amd import host
+    from oracle import bindings as ob
+    soup = conftest.load_model("soup")
+    lo, hi = raygen.scene_bounds(soup)
+    c = (lo + hi) / 2
+    q = np.zeros((4, 8), np.float32)
+    q[:, 0] = hi[0]
+    q[:, 1] = [lo[1], hi[1], hi[1], lo[1]]
+    q[:, 2] = [lo[2], lo[2], hi[2], hi[2]]
+    q[:, 3] = 1.0
+    quad = host.model_from_arrays(q, np.array([0, 1, 2, 0, 2, 3], np.uint32))
+    model = host.merge_models([soup, quad])
+    assert model.meshes[1].nodes["is_leaf"][0]
+    sc = gpu.Scene(model, device=0)
+    orc = ob.OracleScene(model)
+    n = 4096
+    z = (c[2] + np.linspace(-0.2, 0.2, n) * (hi[2] - lo[2])).astype(np.float32)
+    tgt = np.stack([np.full(n, hi[0], np.float32), np.full(n, hi[1], np.float32), z], 1)     # points of the quad's edge y = hi
+    org = np.repeat(np.array([[hi[0] + 1.0, hi[1] - 1.0, c[2]]], np.float32), n, 0)          # one origin: a coherent bundle
+    d = (tgt - org).astype(np.float32)
+    d[d[:, 2] == 0, 2] = 1e-6
+    oid, otuv = orc.closest_hit(org, d, threads=4)
+    assert (oid[:, 0] == 1).mean() > 0.5      # the reference finds the quad on most of them (the edge's u or v comes out as 0 or just inside)
+    for mode in (0, 1, 4):
+        sc.set_option("traversal", mode)
+        ids, tuv = hits_to_arrays(sc.closest_hit(org, d))
+        assert np.array_equal(ids, oid), f"traversal {mode}: ids"
+        assert np.array_equal(bits(tuv), bits(otuv)), f"traversal {mode}: t,u,v bits"
+        assert np.array_equal(sc.any_hit(org, d).astype(bool), oid[:, 0] != gpu.INVALID), f"traversal {mode}: any hit"
+    sc.close()
 
 
 @pytest.mark.parametrize("name", SCENES)

@@ -9,7 +9,7 @@ import conftest
 from oracle import bindings as ob
 
 SCENES = ["cornell", "view_test", "hindu", "nanosuit", "soup"]
-BATCHES = ["primary", "bounce", "shadow", "box", "edge"]
+BATCHES = ["primary", "bounce", "shadow", "box", "edge", "grazing"]
 
 
 def golden(name):

@@ -10,8 +10,9 @@ import conftest
 import raygen
 from oracle import bindings as ob
 
-BATCHES = ["primary", "bounce", "shadow", "box", "edge"]
+BATCHES = ["primary", "bounce", "shadow", "box", "edge", "grazing"]
 SLACK = 2.0 ** -7    # kWideSlack
+PLAIN, GUARDED = 1, 2  # the model's culls: without the guard (option wide_guard = 0) and as the product runs them
 
 
 def bits(a):
@@ -29,17 +30,16 @@ def test_wide_model_matches_the_golden_vectors(name):
     g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
     for b in BATCHES:
         o, d = g[f"{b}_org"], g[f"{b}_dir"]
-        ids, tuv, st = wm.closest_hit(o, d, cull=True, threads=4, kappa=SLACK)
+        ids, tuv, st = wm.closest_hit(o, d, cull=GUARDED, threads=4, kappa=SLACK)
         taken = ids[:, 0] != ob.WideModel.NOT_TAKEN
-        if b != "edge":
-            assert taken.all(), f"{name}/{b}"
-        else:
+        if b == "edge":
             assert taken.mean() < 0.9
-        if name == "hindu" and b == "edge":
-            # Rays laid exactly into the plane of this flat grid of quads: the reference's own t for the
-            # triangles it "hits" edge-on is rounding noise (tens of box sizes off).  The culling margin
-            # does not cover those; the GPU test of the same batch shows what the kernels do with it.
-            continue
+        elif b == "grazing":
+            assert taken.mean() > 0.5     # (some start beyond the origin bound, a few scene sizes back)
+        else:
+            assert taken.all(), f"{name}/{b}"
+        # (hindu/edge holds rays laid exactly into the plane of a flat grid of quads: the reference's own t for the
+        # triangles it "hits" edge-on is rounding noise, tens of box sizes off -- the walk's guard is what covers those)
         assert np.array_equal(ids[taken], g[f"{b}_ids"][taken]), f"{name}/{b}: ids"
         assert np.array_equal(bits(tuv[taken]), bits(g[f"{b}_tuv"][taken])), f"{name}/{b}: t,u,v bits"
 
@@ -61,10 +61,15 @@ def test_wide_model_against_the_oracle_on_surface_rays(name):
     o = (p + 1e-3 * nr / np.where(ln > 0, ln, 1)).astype(np.float32)
     o, d = raygen.rays_to_surface(o, model, seed=8)
     oid, otuv, counters = sc.closest_hit(o, d, threads=8, count=True)
-    ids, tuv, st = wm.closest_hit(o, d, cull=True, threads=8, kappa=SLACK)
+    ids, tuv, st = wm.closest_hit(o, d, cull=GUARDED, threads=8, kappa=SLACK)
     assert np.array_equal(ids, oid) and np.array_equal(bits(tuv), bits(otuv))
-    assert st["tris"] < 0.25 * counters[1] and st["nodes"] < 0.25 * counters[0]      # a quarter of the reference's tests at most
     assert st["max_stack"] <= wm.stack_need
+    # the work the walk saves: with the guard a scene of large, bumpy triangles (nanosuit) keeps about half of the reference's
+    # tests on these rays, a scene of small ones (the soup: the guard never fires) an eighth; without the guard a quarter at most
+    assert st["tris"] < 0.75 * counters[1] and st["nodes"] < 0.5 * counters[0]
+    ids, tuv, st = wm.closest_hit(o, d, cull=PLAIN, threads=8, kappa=SLACK)
+    assert np.array_equal(ids, oid) and np.array_equal(bits(tuv), bits(otuv))
+    assert st["tris"] < 0.25 * counters[1] and st["nodes"] < 0.25 * counters[0]
 
 
 def test_wide_tree_structure():

@@ -3,7 +3,9 @@
 as many rays as one cares to wait for: rays from surface points to surface points (they graze the surfaces they
 leave and reach), rays from surface points in random directions, and rays across the scene's box, generated on
 the device.  Prints the number of rays whose five output words differ.
-Usage: python tools/ab/stress_wide.py [log2 of rays per scene and kind = 28] [scene ...]"""
+Usage: python tools/ab/stress_wide.py [log2 of rays per scene and kind = 28] [scene ...]
+Environment: STRESS_KINDS (kinds to run, separated by ';'), WIDE_GUARD (0: the wide walk without its guard),
+STRESS_DUMP (file under gpurun_out/ that receives the rays that differ, per scene and kind, as an .npz)."""
 import os
 import sys
 import time
@@ -25,9 +27,12 @@ def main():
     rounds = max(1, (1 << total_log2) // n)
     g = torch.Generator(device="cuda"); g.manual_seed(12345)
     grand = 0
+    dump = {}
     for name in scenes:
         model = conftest.load_model(name)
         sc = api.Scene(model, device=0)
+        if os.environ.get("WIDE_GUARD"):
+            sc.set_option("wide_guard", int(os.environ["WIDE_GUARD"]))
         tris = torch.from_numpy(np.concatenate([m.vertices[m.indices.reshape(-1, 3), :3] for m in model.meshes if m.n_triangles])).cuda()
         lo = tris.reshape(-1, 3).min(0).values; hi = tris.reshape(-1, 3).max(0).values
 
@@ -84,6 +89,10 @@ def main():
                 got = sc.closest_hit(o, d)
                 bad = int((want != got).any(1).sum())
                 kinds[kind] += bad
+                if bad and os.environ.get("STRESS_DUMP"):
+                    sel = (want != got).any(1).nonzero()[:, 0]
+                    key = f"{name}/{kind}"
+                    dump.setdefault(key + "/org", []).append(o[sel].cpu().numpy()); dump.setdefault(key + "/dir", []).append(d[sel].cpu().numpy())
                 if bad:
                     i = int((want != got).any(1).nonzero()[0])
                     print(f"  {name} / {kind}: ray o={o[i].tolist()} d={d[i].tolist()} unculled {want[i].tolist()} wide {got[i].tolist()}", flush=True)
@@ -92,6 +101,11 @@ def main():
         print(f"{name}: {rounds * n} rays per kind, rays that differ: {kinds}", flush=True)
         grand += sum(kinds.values())
         sc.close()
+    if dump:
+        path = os.path.join(ROOT, "gpurun_out", os.environ["STRESS_DUMP"])
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        np.savez_compressed(path, **{k: np.concatenate(v) for k, v in dump.items()})
+        print("rays that differ written to", path)
     print("rays that differ in total:", grand)
     sys.exit(1 if grand else 0)
 

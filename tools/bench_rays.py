@@ -2,7 +2,8 @@
 """Closest-hit throughput (Mrays/s) of the traversal kernels on device-resident ray batches,
 timed with the library's HIP events.  Usage: python tools/bench_rays.py [scene ...]
 Environment: RAYS_LOG2 (batch size, default 22), RAYS_ONLY (name of the one batch to run),
-RAYS_MODES (comma-separated traversal options to run, default "1,4,0,2")."""
+RAYS_MODES (comma-separated traversal options to run, default "1,4,0,2"),
+WIDE_GUARD (0: the wide walk without its guard, option "wide_guard")."""
 import os
 import sys
 import time
@@ -24,6 +25,8 @@ def main():
     for name in scenes:
         model = conftest.load_model(name)
         sc = api.Scene(model, device=0)
+        if os.environ.get("WIDE_GUARD"):
+            sc.set_option("wide_guard", int(os.environ["WIDE_GUARD"]))
         eye, look, up, yv = raygen.default_camera(model) if name != "cornell" else ([-0.10141, 1, 3.00498], [-0.10141, 1, 2.00498], [0, 1, 0], 1.0)
         cam = api.camera_vectors(eye, look, up, yv, 16 / 9)
         o1, d1 = raygen.primary_rays(cam, 1920, 1080, n, seed=1)
