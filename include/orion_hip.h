@@ -150,14 +150,16 @@ int orion_hip_closest_hit(OrionScene* scene, const float* org_any, const float* 
 int orion_hip_any_hit(OrionScene* scene, const float* org_any, const float* dir_any,
                       uint32_t n, uint8_t* occluded_any);
 
-/* orion_hip_closest_hit for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same results as
+/* orion_hip_closest_hit for callers that cannot allocate (tight serving loops, harnesses that forbid
+ * hipMalloc after start-up).  It has no counterpart in the reference.  Same results as
  * orion_hip_closest_hit.  org, dir and out must be DEVICE arrays; n is at most 16 777 216 (2^24) rays per
  * call, larger batches are refused.  On large scenes the kernels' work words and chunk list (what the
  * other entry point keeps in a buffer it allocates) live in a 1 MiB array inside the library's code
  * object, one copy per GPU, held until the process ends.  The call makes no hipMalloc / hipFree and
- * records no profiling events.  Every call on one GPU shares that GPU's array: calls that overlap on one
- * GPU (two scenes, two threads) race -- serialise them. */
+ * records no profiling events.  It is NOT something to record into a HIP graph: it launches on the scene's
+ * own stream and returns once the results are in place.  Every call on one GPU shares that GPU's array:
+ * a call that finds it in use by another call (another scene, another thread) fails with code 4 and
+ * touches nothing -- serialise calls per GPU. */
 int orion_hip_closest_hit_noalloc(OrionScene* scene, const float* org, const float* dir,
                                   uint32_t n, OrionHit* out);
 
@@ -188,8 +190,13 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *                 triangles; slow on batches, it exists to test the walk the tail kernel uses),
  *                 4 = ordered, distance-culled traversal of the 4-wide tree (scenes above 64 nodes whose
  *                 trees keep every child box inside its parent's); what 0 picks for scenes above 384 nodes.
- *                 Returns what 1 returns on every natural batch tested; rays aimed along a triangle's plane
- *                 at a slope below 1e-5 can come out differently (the reference's own answer is rounding noise there)
+ *                 Returns what 1 returns, bit for bit, on every ray (see "wide_guard")
+ *   "wide_guard"  1 (default): the 4-wide walk visits a slot whatever its box says when the slot may hold a triangle
+ *                 whose test is ill conditioned for the ray (a ray within about 0.03 degrees of the triangle's plane,
+ *                 where the reference's own t, u, v are rounding noise that can land anywhere); with it every skip of
+ *                 the walk is proven and the walk returns the reference's bits.  0: the walk trusts its boxes (1.3 to
+ *                 2.6 times faster on scenes of large triangles; differs from the reference on a few rays in 10^9 aimed
+ *                 along triangle planes -- 349 of 2^30 on a 19 058-triangle model, none on any natural batch tested)
  *   "tail_paths"  a render batch hands its remaining paths to the one-path-per-wave
  *                 tail kernel once at most this many are left (0 = never; small scenes only)
  *   "batch_paths" upper bound on paths in flight per render batch (default 256 Mi: up to 36 GiB of queues
@@ -207,9 +214,7 @@ int orion_hip_profile_read(OrionScene* scene, OrionKernelStats* stats);
  *                 triangle of a leaf while it tests the present one; 0 (default): it fetches each when it gets there
  *   "queue_budget_mib" memory a render call's queues may take, in MiB (0, the default: three quarters of
  *                 the device's free memory); the call halves its samples per batch until they fit
- *   "fail_at_bounce" test hook: the n-th bounce a render call launches from now on fails (once) with
- *                 code 3, whatever is in flight; the call waits for that work and the handle stays usable
- * Results never depend on these. */
+ * Results never depend on these, with the one exception stated under "wide_guard" = 0. */
 int orion_hip_scene_set_option(OrionScene* scene, const char* name, int64_t value);
 
 /* Message for the most recent failure on the calling thread ("" if none). */

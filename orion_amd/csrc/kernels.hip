@@ -7,7 +7,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -81,6 +83,7 @@ constexpr uint32_t kNoAllocWords = kWorkWords + kNoAllocMaxRays / 64;     // the
 constexpr int kMaxDevices = 64;
 uint32_t* g_noalloc_scratch[kMaxDevices] = {};
 std::mutex g_noalloc_mutex;
+std::atomic<int> g_noalloc_busy[kMaxDevices] = {};   // 1 while a call uses the device's copy: a second call is refused, not raced
 
 } // namespace
 
@@ -119,7 +122,7 @@ struct OrionScene {
     uint64_t batch_paths = 256u << 20;    // paths in flight per batch (128 B of queues each; less where the device's free memory asks for it)
     uint32_t queue_parts_log2 = kPartsLog2;   // partitions of a render batch's queues (2^n; FrameParams::part_log2)
     uint32_t overlap_below = 128u << 20;   // start the next batch on the other lane once this few rays are left (0: never)
-    uint32_t fail_at_bounce = 0;          // test hook: the n-th bounce launched from now on fails (once)
+    uint32_t fail_at_bounce = 0;          // test hook (ORION_HIP_TEST_HOOKS=1 only): the n-th bounce of the next render call fails
     uint64_t queue_budget = 0;            // bytes the render queues may take (0: three quarters of the device's free memory)
     bool draw_rays = true;                // large scenes: bounce rays are handed to lanes as they finish (k_extend_wide)
     bool wave_ahead = false;              // large scenes: the primary rays' wave-synchronous walk fetches one record ahead (slower since a wave holds one pixel's samples)
@@ -778,7 +781,11 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
         s->queue_budget = (uint64_t)value << 20;
         return 0;
     }
+    // Test hook, not part of the documented options: only a process started with ORION_HIP_TEST_HOOKS=1 can arm it, for the
+    // next render call only.  The n-th bounce that call launches fails with code 3, whatever is in flight.
     if (!std::strcmp(name, "fail_at_bounce")) {
+        const char* hooks = std::getenv("ORION_HIP_TEST_HOOKS");
+        if (!hooks || std::strcmp(hooks, "1") != 0) return fail(1, "set_option: unknown option 'fail_at_bounce'");
         if (value < 0 || value > (int64_t)1 << 30) return fail(1, "set_option: fail_at_bounce out of range");
         s->fail_at_bounce = (uint32_t)value;
         return 0;
@@ -843,7 +850,15 @@ int orion_hip_closest_hit_noalloc(OrionScene* s, const float* d_org, const float
     if (qm == MODE_WIDE || qm == MODE_ADAPT_WIDE) {
         uint32_t* work = (s->device >= 0 && s->device < kMaxDevices) ? g_noalloc_scratch[s->device] : nullptr;
         if (!work) return fail(2, "closest_hit_noalloc: no scratch on this device");
-        if (int rc = launch_query_wide<false>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, d_out, nullptr, work, true)) return rc;
+        // One copy of the scratch per GPU: a call that finds it in use (another scene, another thread) is refused.
+        if (g_noalloc_busy[s->device].exchange(1, std::memory_order_acquire) != 0)
+            return fail(4, "closest_hit_noalloc: this GPU's scratch is in use by another call (calls on one GPU must not overlap)");
+        int rc = launch_query_wide<false>(s, qm == MODE_ADAPT_WIDE, d_org, d_dir, n, d_out, nullptr, work, true);
+        const hipError_t e = rc ? hipSuccess : hipStreamSynchronize(s->stream);   // the scratch is free once the kernels are done
+        g_noalloc_busy[s->device].store(0, std::memory_order_release);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(2, std::string("closest_hit_noalloc: ") + hipGetErrorString(e));
+        return 0;
     } else {   // the other walks keep nothing beyond their inputs and outputs
         with_query_mode(qm, [&](auto M) {
             hipLaunchKernelGGL(k_closest_api<decltype(M)::value>, dim3(grid_for(n)), dim3(kBlock), 0, s->stream, s->view, d_org, d_dir, n, d_out);
@@ -1121,6 +1136,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         return 0;
     };
     const int rc = run();
+    s->fail_at_bounce = 0;   // (the test hook never outlives the call it was armed for)
     if (rc != 0) {
         const std::string why = g_error;
         for (Lane& L : s->lane) (void)hipStreamSynchronize(L.stream);

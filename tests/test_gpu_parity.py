@@ -690,11 +690,16 @@ def test_quick_reciprocals_return_the_divisions_bits(gpu, name, modes):
     sc.set_option("traversal", 0)
 
 
-def test_a_failed_render_leaves_the_handle_usable(gpu):
+def test_a_failed_render_leaves_the_handle_usable(gpu, monkeypatch):
     """A render call that fails half way (the test hook makes the n-th bounce launch fail; an allocation for the
     next batch failing ends the same way) has launches of one or both lanes in flight.  The call must wait for
-    them, report, and the next call on the same handle must give the bits of a fresh one."""
+    them, report, and the next call on the same handle must give the bits of a fresh one.  The hook can only be
+    armed in a process that asks for it, and for one call."""
     sc = gpu.Scene(conftest.load_model("cornell"), device=0)
+    monkeypatch.delenv("ORION_HIP_TEST_HOOKS", raising=False)
+    with pytest.raises(gpu.OrionError, match="unknown option"):
+        sc.set_option("fail_at_bounce", 1)
+    monkeypatch.setenv("ORION_HIP_TEST_HOOKS", "1")
     eye, look, up, yv = CORNELL_CAM
     W, H, spp = 256, 144, 12
     cam = gpu.camera_vectors(eye, look, up, yv, W / H)
@@ -706,7 +711,6 @@ def test_a_failed_render_leaves_the_handle_usable(gpu):
         sc.set_option("fail_at_bounce", n)
         with pytest.raises(gpu.OrionError, match="injected failure"):
             sc.render(cam, W, H, 0, spp, 2, 30, seed=21)
-        sc.set_option("fail_at_bounce", 0)
         img = sc.render(cam, W, H, 0, spp, 2, 30, seed=21)
         assert np.array_equal(bits(ref), bits(img)), n
     sc.close()
