@@ -17,9 +17,12 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
                 (one batch at a time, so that no launch shares the chip with another batch's)
   issue         the bound that actually holds: vector-instruction issue, against the guide's and the measured rate
   ray_batches   closest-hit Mrays/s of the ray-query entry point on R1/R2/R3 batches of five scenes
+  configs       the other BASELINE.json configs (c0, c2, c3, c3b, c4) at their full size: a few frames each, samples/s,
+                the dominant kernel and its algorithmic GB/s
   cpu_baseline  the oracle's render of a bounded sample of the same frame on the host cores
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -74,6 +77,88 @@ def cpu_baseline(model, cam, target_s=12.0):
             "box_tests_per_sample": float(counters[0]) / (w * h * 4), "triangle_tests_per_sample": float(counters[1]) / (w * h * 4)}
 
 
+def framing_camera(model):
+    """eye / look-at / up / yview / aspect of a camera on the +z side whose frame is the model's bounding box (the
+    reference's camera: the frame is yview high at distance 1, orion/raytracer.cpp:212-238), so that most primary rays
+    meet the model."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import raygen
+    lo, hi = raygen.scene_bounds(model)
+    c = (lo + hi) / 2
+    dx, dy = float(hi[0] - lo[0]), float(hi[1] - lo[1])
+    dist = 1.02 * dy                      # yview = 1: the frame is as high as it is far away
+    eye = np.array([c[0], c[1], hi[2] + dist], np.float32)
+    return eye, c.astype(np.float32), np.array([0, 1, 0], np.float32), 1.0, max(0.05, dx / dy)
+
+
+def source_sha():
+    """One hash over the kernel sources: the per-ray / per-vertex constants of the counter passes in profiles/ belong to
+    the sources they were taken with."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "orion_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def git_blob_sha(path):
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def config_frames(api, device, budget_s=2.5):
+    """The other BASELINE.json configs at their full size (configs/*.rtc, the derived scene files): frames of the config's
+    own spp, as many as fit into about budget_s seconds, then one frame with per-kernel HIP events for the split."""
+    import torch
+    configs = [("c0_cornell_point_256", 16, 1, "configs[0]: Cornell box, point light, 256x256, 16 spp, depth 8"),
+               ("c2_view_test_fhd", 256, 1, "configs[2]: view_test, 1920x1080, 256 spp"),
+               ("c3_nanosuit_fhd", 512, 1, "configs[3]: nanosuit (19 058 triangles, PNG colour maps), 1920x1080, 512 spp, depth 0 as the asset has it"),
+               ("c3b_nanosuit_bounce_fhd", 512, 1, "configs[3] with four mirror bounces: incoherent secondary rays through the deep trees"),
+               ("c4_hindu_4k", 1024, 1, "configs[4]: hindu, 3840x2160, 1024 spp (one GPU renders the whole frame here)")]
+    out = {"note": "one step = one full frame of the config (its own resolution, spp and depth) on one GPU, accumulator in HBM; "
+                   "dominant kernel and algorithmic GB/s from one more frame with per-kernel HIP events, one batch at a time; "
+                   "hbm_frac = algorithmic GB/s / 8 TB/s (64 B per closest-hit query, 64 B per shadow query + 96 B of path state per shaded vertex)"}
+    for name, spp, ls, what in configs:
+        fr = api.load_frame(os.path.join(ROOT, "configs", name + ".rtc"), load_textures=True)
+        w, h, depth = fr.rtc.xres, fr.rtc.yres, max(0, fr.rtc.recursion_level)
+        sc = api.Scene(fr.model, device=device)
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+
+        def frame():
+            sc.render(fr.camera12, w, h, 0, spp, ls, depth, seed=1, lights=fr.rtc.lights, accum=acc)
+        frame()                                # untimed: the queues are sized on the first call
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        frame()
+        torch.cuda.synchronize(); one = time.perf_counter() - t0
+        frames = int(max(2, min(50, budget_s / max(one, 1e-4))))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(frames):
+            frame()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        sc.set_option("overlap_below", 0)
+        sc.profile(True)
+        frame()
+        torch.cuda.synchronize()
+        st = sc.profile_read()
+        sc.profile(False)
+        per_vertex = BYTES_PER_RAY * (st["shadow"]["items"] / max(1, st["shade"]["items"])) + BYTES_PER_VERTEX_STATE
+        alg = {"closest_hit": st["closest_hit"]["items"] * BYTES_PER_RAY, "shade": st["shade"]["items"] * per_vertex}
+        kern = {k: v for k, v in st.items() if v["launches"] and v["ms"] > 0}
+        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
+        res = {"workload": what, "resolution": [w, h], "spp": spp, "max_depth": depth, "lights": len(fr.rtc.lights),
+               "triangles": int(fr.model.n_triangles), "frames": frames, "ms_per_frame": 1e3 * dt / frames,
+               "samples_per_s": w * h * spp * frames / dt,
+               "rays_per_sample": (st["closest_hit"]["items"] + st["shadow"]["items"]) / (w * h * spp),
+               "kernel_ms": {k: round(v["ms"], 3) for k, v in kern.items()}, "dominant_kernel": dom}
+        if dom in alg and kern[dom]["ms"] > 0:
+            res["algorithmic_GBs"] = alg[dom] / (kern[dom]["ms"] * 1e-3) / 1e9
+            res["hbm_frac"] = res["algorithmic_GBs"] / HBM_PEAK_GBS
+        out[name] = res
+        sc.close()
+        del acc
+    return out
+
+
 def ray_batches(api, log2_rays=20, log2_large=22):
     """Closest-hit throughput of the ray-query entry point (device-resident rays, the library's HIP events) on the
     R1 / R2 / R3 batches of five scenes, with the HBM fraction of the 64 algorithmic bytes per ray."""
@@ -83,15 +168,20 @@ def ray_batches(api, log2_rays=20, log2_large=22):
     import raygen
     n = 1 << log2_rays
     out = {"rays_per_batch": n, "bytes_per_ray": BYTES_PER_RAY,
-           "note": "R1 jittered primary rays of random pixels (1920x1080 camera framing the scene), R2 cosine-weighted bounce rays "
+           "note": "R1 jittered primary rays of random pixels (Cornell: the README camera; other scenes: a camera on the +z side whose frame "
+                   "is the model's bounding box), R2 cosine-weighted bounce rays "
                    "from their hit points in random order, R3 rays from those points towards uniform surface points; "
                    "Mrays/s = rays / average launch time over 5 launches (HIP events); hbm_frac = Mrays/s x 64 B / 8 TB/s"}
     for name in ("cornell", "view_test", "hindu", "nanosuit", "soup"):
         model = conftest.load_model(name)
         sc = api.Scene(model, device=torch.cuda.current_device())
-        eye, look, up, yv = CAMERA if name == "cornell" else raygen.default_camera(model)
-        cam = api.camera_vectors(eye, look, up, yv, W / H)
-        o1, d1 = raygen.primary_rays(cam, W, H, n, seed=1)
+        if name == "cornell":
+            eye, look, up, yv = CAMERA
+            aspect = W / H
+        else:
+            eye, look, up, yv, aspect = framing_camera(model)
+        cam = api.camera_vectors(eye, look, up, yv, aspect)
+        o1, d1 = raygen.primary_rays(cam, max(16, int(round(H * aspect))), H, n, seed=1)
         h = sc.closest_hit(o1, d1)
         nrm = np.zeros((n, 3), np.float32)
         for mi, m in enumerate(model.meshes):
@@ -146,7 +236,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)     # (20 frames: a timed region of about 8 s on one GPU)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp", type=int, default=FULL_SPP, help="samples per pixel of a frame (one step); the headline is 2048")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel of a frame (one step); default: the config's (c1: 2048, c4: 1024)")
+    ap.add_argument("--config", default="c1", choices=["c1", "c4"],
+                    help="c1 (default, the headline): Cornell FHD 2048 spp, BASELINE.json configs[1]; c4: hindu 3840x2160 1024 spp, configs[4]")
+    ap.add_argument("--tiles", default="", metavar="NXxNY", help="shard a frame by image tile x sample chunk over the ranks (e.g. 4x2) "
+                    "instead of by sample range alone; BASELINE.json configs[4] asks for it")
     ap.add_argument("--traversal", type=int, default=0, help="0 auto, 1 per-lane, 2 wave-synchronous")
     ap.add_argument("--tail-paths", type=int, default=-1, help="override the library's tail hand-over threshold (A/B runs)")
     ap.add_argument("--overlap-below", type=int, default=-1, help="override the library's two-lane overlap threshold (A/B runs; 0 = one lane)")
@@ -154,6 +248,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (per-kernel HIP-event timings, roofline)")
     ap.add_argument("--no-ray-batches", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (c0, c2, c3, c3b, c4)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
@@ -178,9 +273,22 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    model = host.load_model(os.path.join(ROOT, "tests", "golden", "assets", "cornell-box", "cornell-box.obj"))
-    eye, look, up, yv = CAMERA
-    cam = api.camera_vectors(eye, look, up, yv, W / H)
+    from orion_amd import dist as odist
+    global W, H, MAX_DEPTH, LIGHT_SAMPLES
+    lights = None
+    if args.config == "c4":
+        fr = api.load_frame(os.path.join(ROOT, "configs", "c4_hindu_4k.rtc"), load_textures=True)
+        model, cam, lights = fr.model, fr.camera12, fr.rtc.lights
+        W, H, MAX_DEPTH, LIGHT_SAMPLES = fr.rtc.xres, fr.rtc.yres, max(0, fr.rtc.recursion_level), 1
+        full_spp = 1024
+    else:
+        model = host.load_model(os.path.join(ROOT, "tests", "golden", "assets", "cornell-box", "cornell-box.obj"))
+        eye, look, up, yv = CAMERA
+        cam = api.camera_vectors(eye, look, up, yv, W / H)
+        full_spp = FULL_SPP
+    tiles = tuple(int(x) for x in args.tiles.lower().split("x")) if args.tiles else None
+    if tiles is not None and (len(tiles) != 2 or min(tiles) < 1):
+        raise SystemExit("--tiles wants NXxNY, e.g. 4x2")
     scene = api.Scene(model, device=local)
     scene.set_option("traversal", args.traversal)
     if args.tail_paths >= 0:
@@ -195,8 +303,14 @@ def main():
         scene.set_option("overlap_below", 4 << 20)
     accums = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
     pending = [None] * len(accums)
-    spp = args.spp
-    s_begin, s_end = spp * rank // world, spp * (rank + 1) // world     # this rank's share of every frame
+    spp = args.spp or full_spp
+    # This rank's share of every frame: a range of sample indices of the whole image, or (--tiles) its cells of the
+    # tile x sample-chunk grid (orion_amd/dist.py: shard_plan).
+    plan = odist.shard_plan(spp, W, H, rank, world, tiles)
+    my_samples = sum((e - b) * ((r[2] - r[0]) * (r[3] - r[1]) if r else W * H) for r, b, e in plan)
+
+    def render_into(accum, b, e, tile):
+        scene.render(cam, W, H, b, e, LIGHT_SAMPLES, MAX_DEPTH, seed=1, lights=lights, tile=tile, accum=accum)
 
     def step(index):
         k = index % len(accums)
@@ -204,9 +318,8 @@ def main():
             pending[k].wait(); pending[k] = None
         accums[k].zero_()
         # (every frame is rendered with the same sample indices: the frames of the timed region are repetitions)
-        scene.render(cam, W, H, s_begin, s_end, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accums[k])
-        if world > 1:                    # the frame's one exchange: sum of the radiance accumulators
-            pending[k] = dist.all_reduce(accums[k], async_op=True)
+        odist.render_plan(render_into, plan, accums[k])
+        pending[k] = odist.reduce_async(accums[k])    # the frame's one exchange: sum of the radiance accumulators (None on one rank)
 
     def fence():
         for k, w in enumerate(pending):
@@ -232,28 +345,47 @@ def main():
 
     samples = W * H * spp * args.steps
     value = samples / dt
+    if args.config == "c4":
+        what = ("hindu 3840x2160 point-light frame, %d spp, depth %d (BASELINE.json configs[4]); one step = one full frame" % (spp, MAX_DEPTH))
+        metric = "samples/s (pixel-samples per second, hindu 3840x2160, %d-spp frames)" % spp
+    else:
+        what = ("cornell-box BRDF path tracer 1920x1080, %d spp, max depth 100, 2 light samples "
+                "(BASELINE.json configs[1], the reference's README render); one step = one full frame" % spp)
+        metric = "samples/s (pixel-samples per second, Cornell box 1920x1080 BRDF path tracer, %d-spp frames)" % spp
     out = {
-        "metric": "samples/s (pixel-samples per second, Cornell box 1920x1080 BRDF path tracer, %d-spp frames)" % spp,
+        "source_sha": source_sha(),
+        "metric": metric,
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": value / PUBLISHED_SAMPLES_PER_S, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cornell-box BRDF path tracer 1920x1080, %d spp, max depth 100, 2 light samples "
-                               "(BASELINE.json configs[1], the reference's README render); one step = one full frame" % spp,
-                   "spp": spp, "spp_per_gpu": s_end - s_begin, "seed": 1, "rng": "philox4x32-10 counter",
-                   "sharding": "sample-index ranges per rank + one RCCL all-reduce of the accumulator per frame"},
+        "vs_baseline": (value / PUBLISHED_SAMPLES_PER_S) if args.config == "c1" else None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": what,
+                   "spp": spp, "samples_this_rank": my_samples, "seed": 1, "rng": "philox4x32-10 counter",
+                   "sharding": ("%dx%d image tiles x %d sample chunks dealt round-robin over the ranks" % (tiles[0], tiles[1], world) if tiles
+                                else "sample-index ranges per rank") + " + one RCCL all-reduce of the accumulator per frame"},
         "frame_wall_s": dt / max(1, args.steps),
         "per_gpu_samples_per_s": value / world,
     }
     if rank == 0:
         E = sum(1 for m in model.meshes if np.any(model.materials[m.material].emissive != 0))
-        if not args.no_profile:
-            # The profiled pass: 128 spp of the same frame, batches one at a time (under the two-lane overlap of the timed
-            # region a launch's duration includes the time it shares the chip with the other batch's launches).
+        if not args.no_profile and args.config == "c1":
+            # The profiled passes: PROF_SPP samples of the same frame (four batches) with per-kernel HIP events, first on the timed region's own
+            # schedule (two lanes: the next batch's head runs beside the current batch's thin tail, so a launch's duration
+            # includes the time it shares the chip), then one batch at a time (no launch shares the chip: these are the
+            # durations the roofline is computed from).
+            PROF_SPP = 512
+            scene.profile(True)
+            accums[0].zero_()
+            t1 = time.perf_counter()
+            scene.render(cam, W, H, 0, PROF_SPP, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accums[0])
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            stats2 = scene.profile_read()
+            scene.profile(False)
             scene.set_option("overlap_below", 0)
             scene.profile(True)
             accums[0].zero_()
             t1 = time.perf_counter()
-            scene.render(cam, W, H, 0, 128, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accums[0])
+            scene.render(cam, W, H, 0, PROF_SPP, LIGHT_SAMPLES, MAX_DEPTH, seed=1, accum=accums[0])
             torch.cuda.synchronize()
             dtp = time.perf_counter() - t1
             stats = scene.profile_read()
@@ -262,10 +394,11 @@ def main():
             vertices = stats["shadow"]["items"] // max(1, LIGHT_SAMPLES * E)
             units = {"closest_hit": ("k_extend", stats["closest_hit"]["items"], BYTES_PER_RAY),
                      "shade": ("k_shade", vertices, BYTES_PER_RAY * LIGHT_SAMPLES * E + BYTES_PER_VERTEX_STATE)}
-            pmc = {}
-            for f in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            pmc, pmc_file = {}, None
+            for f in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
                 try:   # HBM bytes per unit measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (see profiles/)
                     pmc = json.load(open(os.path.join(ROOT, "profiles", f)))
+                    pmc_file = f
                     break
                 except OSError:
                     pass
@@ -282,17 +415,40 @@ def main():
                     if kname in pmc:
                         per = pmc[kname]["hbm_read_bytes_per_item"] + pmc[kname]["hbm_write_bytes_per_item"]
                         kern[kname]["pmc_hbm_bytes_per_launch"] = per * items / launches
+                        kern[kname]["pmc_hbm_GBs"] = per * items / launches / (avg_ms * 1e-3) / 1e9
             if kern:
                 dom = max(kern, key=lambda k: kern[k]["ms"])
+                traffic = kern[dom].get("pmc_hbm_bytes_per_launch")
                 out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["algorithmic_GBs"], "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": kern[dom]["algorithmic_GBs"] / HBM_PEAK_GBS,
-                                   "traffic": kern[dom].get("pmc_hbm_bytes_per_launch"),
-                                   "note": "achieved = algorithmic bytes per launch / average launch duration (HIP events on the library's "
-                                           "stream) in a separate profiled pass of 128 spp of the same frame, one batch at a time; traffic = "
-                                           "HBM bytes per launch from the PMC passes in profiles/ (FETCH_SIZE doubled per the gfx950 "
-                                           "correction).  The kernel is bound by instruction issue, not by HBM: see `issue`."}
+                                   "traffic": traffic,
+                                   "traffic_GBs": kern[dom].get("pmc_hbm_GBs"),
+                                   "traffic_frac": (kern[dom]["pmc_hbm_GBs"] / HBM_PEAK_GBS) if traffic else None,
+                                   "binding_limit": "valu issue (see `issue`), not HBM",
+                                   "note": "achieved / frac = ALGORITHMIC bytes per launch / average launch duration (HIP events on the library's "
+                                           "stream) in a profiled pass of 512 spp of the same frame, one batch at a time.  For k_shade 128 of the 224 "
+                                           "algorithmic bytes per vertex are the ray and hit records of its two light-sample queries, which are traced "
+                                           "in registers and never reach HBM: traffic / traffic_GBs / traffic_frac = the HBM bytes the kernel really "
+                                           "moves per launch (PMC passes in profiles/, FETCH_SIZE doubled per the gfx950 correction) and that as a rate "
+                                           "and as a fraction of 8 TB/s -- the number to read as HBM utilisation."}
+                if pmc_file:
+                    cur = source_sha()
+                    taken = pmc.get("source_sha")
+                    out["pmc_constants"] = {"file": "profiles/" + pmc_file, "git_blob": git_blob_sha(os.path.join(ROOT, "profiles", pmc_file)),
+                                            "taken_at_source_sha": taken, "current_source_sha": cur, "stale": taken != cur,
+                                            "note": "bytes and vector instructions per ray / per vertex come from counter passes of an earlier run; "
+                                                    "stale = the kernel sources have changed since (traffic and `issue` then describe the older kernels)"}
                 out["kernels"] = kern
-                out["profiled_pass"] = {"spp": 128, "wall_s": dtp, "samples_per_s": W * H * 128 / dtp}
+                ksum = sum(kern[k]["ms"] for k in kern) * 1e-3
+                ksum2 = sum(stats2[n]["ms"] for n in units if stats2[n]["launches"]) * 1e-3
+                out["profiled_pass"] = {"spp": PROF_SPP, "wall_s": dtp, "samples_per_s": W * H * PROF_SPP / dtp, "schedule": "one batch at a time",
+                                        "kernel_sum_s": ksum, "projected_frame_s": dtp * spp / PROF_SPP}
+                out["profiled_pass_two_lanes"] = {"spp": PROF_SPP, "wall_s": dt2, "samples_per_s": W * H * PROF_SPP / dt2, "schedule": "as the timed region",
+                                                  "kernel_sum_s": ksum2, "projected_frame_s": dt2 * spp / PROF_SPP,
+                                                  "note": "the timed frames run on this schedule: the next batch's first two bounces run beside the current "
+                                                          "batch's thin tail.  A frame is therefore SHORTER than the one-at-a-time pass projects (its tails are "
+                                                          "hidden), while the sum of its kernels' HIP-event durations is LONGER (overlapped launches each count "
+                                                          "the time they share the chip): the roofline and `issue` use the one-at-a-time durations"}
                 if all("valu_wave_instructions_per_item" in pmc.get(k, {}) for k in kern):
                     # what actually bounds the step: vector-instruction issue.  Instructions per ray / vertex from the counter
                     # passes in profiles/, over the kernels' own time in the profiled pass.
@@ -308,13 +464,15 @@ def main():
                                             "the shader clock dropping to 1.86 GHz under that load)"}
                 rays = stats["closest_hit"]["items"] + stats["shadow"]["items"]
                 out["rays"] = {"extend_rays": stats["closest_hit"]["items"], "light_sample_rays": stats["shadow"]["items"],
-                               "per_sample": rays / (W * H * 128),
-                               "Mrays_per_s_per_gpu": rays / (W * H * 128) * value / world / 1e6,
+                               "per_sample": rays / (W * H * PROF_SPP),
+                               "Mrays_per_s_per_gpu": rays / (W * H * PROF_SPP) * value / world / 1e6,
                                "note": "closest-hit queries per pixel-sample (profiled pass) x the timed region's samples/s per GPU; "
                                        "a light-sample query whose shading term is surely zero is answered without a walk and still counted"}
         if world == 1 and not args.no_ray_batches:      # (single-GPU figures: the other ranks would only wait for them)
             out["ray_batches"] = ray_batches(api)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_configs:
+            out["configs"] = config_frames(api, local)
+        if world == 1 and not args.no_cpu_baseline and args.config == "c1":
             out["cpu_baseline"] = cb = cpu_baseline(model, cam)
             if "rays" in out:   # the algorithm's work per closest-hit query (reference counters: orion/avx/sbvh.cpp:8-12)
                 out["rays"]["box_tests_per_ray"] = cb["box_tests_per_sample"] / out["rays"]["per_sample"]

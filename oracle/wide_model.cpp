@@ -158,8 +158,8 @@ bool walk(const Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& 
                     }
                     // a dangerous inner slot the ray's line misses fails the reference's own box test; a dangerous leaf is visited anyway
                     if (danger && !(refs[k] & 0x80000000u) && !met) danger = false;
-                    if (danger && !within) st.danger_slots++;
                     const float cull_t = danger ? -1.0f : a;
+                    if (danger && !within) st.danger_slots++;
                     if (cull && !within && !danger) continue;
                     hit[nh].ref = refs[k]; hit[nh].tmin = (within ? a : 3.0e38f); hit[nh].danger = danger; hit[nh].cull_t = cull_t; nh++;
                 }

@@ -47,6 +47,25 @@ def shard_plan(total_spp: int, width: int, height: int, rank: int, world: int,
     return plan
 
 
+def render_plan(render_fn: Callable, plan, accum):
+    """Render one rank's work list (shard_plan) into `accum`: render_fn(accum, spp_begin, spp_end, tile) ADDS samples."""
+    for rect, b, e in plan:
+        render_fn(accum, b, e, rect)
+    return accum
+
+
+def reduce_async(accum, group=None, reduce_to_all: bool = True):
+    """Start the frame's one exchange, the sum of the accumulators over the process group, and return its work handle
+    (None in a single process).  With the nccl backend this is one RCCL all-reduce over xGMI; the caller may render the
+    next frame into another accumulator meanwhile and calls .wait() before it reads or reuses this one."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None
+    if reduce_to_all:
+        return dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def render_sharded(render_fn: Callable, total_spp: int, width: int, height: int, accum,
                    tiles: Optional[Tuple[int, int]] = None, group=None, reduce_to_all: bool = True):
     """Render this rank's share into `accum` (a torch tensor [H,W,4], zeroed by the caller) and sum
@@ -59,11 +78,8 @@ def render_sharded(render_fn: Callable, total_spp: int, width: int, height: int,
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
-    for rect, b, e in shard_plan(total_spp, width, height, rank, world, tiles):
-        render_fn(accum, b, e, rect)
-    if world > 1:
-        if reduce_to_all:
-            dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
-        else:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, group=group)
+    render_plan(render_fn, shard_plan(total_spp, width, height, rank, world, tiles), accum)
+    work = reduce_async(accum, group=group, reduce_to_all=reduce_to_all)
+    if work is not None:
+        work.wait()
     return accum

@@ -55,6 +55,19 @@ for name, tiles in (("samples", None), ("tiles", (2, 2))):
     odist.render_sharded(render, SPP, W, H, acc, tiles=tiles)
     if dist.get_rank() == 0:
         np.save(os.path.join({out!r}, name + ".npy"), acc.numpy())
+# bench.py's frame step: the rank's cells of the tile x sample-chunk grid, then the sum started asynchronously while the next
+# frame renders into a second accumulator
+plan = odist.shard_plan(SPP, W, H, dist.get_rank(), 2, (3, 2))
+accs = [torch.zeros((H, W, 4), dtype=torch.float32) for _ in range(2)]
+works = []
+for k in range(2):
+    odist.render_plan(render, plan, accs[k])
+    works.append(odist.reduce_async(accs[k]))
+for w in works:
+    w.wait()
+assert torch.equal(accs[0], accs[1])
+if dist.get_rank() == 0:
+    np.save(os.path.join({out!r}, "async_tiles.npy"), accs[0].numpy())
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -71,7 +84,7 @@ def test_two_process_gloo_matches_single_process(tmp_path):
     sc = ob.OracleScene(conftest.load_model("cornell"))
     cam = ob.camera_vectors([-0.10141, 1, 3.00498], [-0.10141, 1, 2.00498], [0, 1, 0], 1.0, 1.5)
     full = sc.render(cam, 48, 32, 0, 6, 2, 8, seed=4, threads=2)
-    for name in ("samples", "tiles"):
+    for name in ("samples", "tiles", "async_tiles"):
         got = np.load(tmp_path / f"{name}.npy")
         assert np.array_equal(got[:, :, 3], full[:, :, 3])
         # same samples, different summation order across ranks

@@ -9,7 +9,7 @@ root=$(pwd)
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 # frames of 128 spp (4 batches) keep the passes short; the counter passes skip the profiled pass and the ray batches
-args="--spp 128 --steps 2 --warmup 1 --no-cpu-baseline --no-ray-batches"
+args="--spp 128 --steps 2 --warmup 1 --no-cpu-baseline --no-ray-batches --no-configs"
 timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}trace -o p -- python3 $root/bench.py $args > $out/${tag}trace.log 2>&1 || { echo "trace pass failed"; exit 1; }
 grep '^{' $out/${tag}trace.log | tail -1 > $out/${tag}trace/bench.json
 pass() {  # name, counters

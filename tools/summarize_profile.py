@@ -79,9 +79,9 @@ def main():
         d = json.load(open(prefix + "trace/bench.json"))
         # The counter passes run the same command as the traced one, and the counters also see the
         # warm-up steps, which bench.py's unit counts leave out.
-        # bench.py's unit counts are those of its profiled pass (128 spp of the frame); the counter passes run
+        # bench.py's unit counts are those of its profiled pass (profiled_pass.spp samples of the frame); the counter passes run
         # steps + warmup frames of config.spp samples and no profiled pass.
-        scale = (d["steps"] + d["warmup"]) * d["config"]["spp"] / 128.0
+        scale = (d["steps"] + d["warmup"]) * d["config"]["spp"] / float(d.get("profiled_pass", {}).get("spp", 128))
         units = {"k_extend": d["kernels"]["k_extend"]["units"] * scale, "k_shade": d["kernels"]["k_shade"]["units"] * scale}
         note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --spp 128 --steps 2 --warmup 1; FETCH_SIZE doubled "
                 "(gfx950 counts half the bytes of wide coalesced reads); item = ray for k_extend, shaded vertex for k_shade")
@@ -92,6 +92,7 @@ def main():
                               "hbm_write_bytes_per_item": agg[k]["WRITE_SIZE"] * 1024 / n, "items": n, "note": note}
                 if "SQ_INSTS_VALU" in agg[k]:   # wave64 vector instructions issued per item
                     traffic[k]["valu_wave_instructions_per_item"] = agg[k]["SQ_INSTS_VALU"] / n
+        traffic["source_sha"] = d.get("source_sha")   # the kernel sources these per-item figures were taken with (bench.py: source_sha)
         json.dump(traffic, open(sys.argv[3], "w"), indent=1)
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
