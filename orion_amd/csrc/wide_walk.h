@@ -14,18 +14,37 @@
 //     "t < best, or t == best and slot > best slot" selects the same triangle with the same t, u, v.
 //   * Skipping.  A slot's decoded box is grown by the scene's pad (it then contains the slot's real box) and further by
 //     kWideSlack times (the origin's distance to the farthest corner of the node's box + two pads).  An inner slot
-//     missed by the ray would fail the reference's own test on the (smaller) real box.  Two more skips
-//     rest on one assumption, that the reference's computed hit point o + t*d of a triangle it accepts
-//     lies inside the triangle's box grown by that much: a leaf whose grown box the ray misses, and any
-//     slot whose grown box begins beyond the best hit so far.  The triangle test's rounding moves the
-//     computed hit by about 1e-5 / (sin(apex angle) * cos(angle to the normal)) of its distance, so the
-//     assumption can only fail for a ray nearly in the plane of a triangle.  That part is measured, not proven: this
-//     walk and the unculled walk agree on every one of 1.6 * 10^10 rays aimed along and across three scenes' surfaces
-//     (tools/ab/stress_wide.py), as does the CPU model of this walk with the reference's restatement
-//     (tests/test_wide_tree.py).  Where it fails, also measured: rays aimed ALONG a triangle's plane at a slope below
-//     1e-5.  There the reference's determinant is a few rounding errors above the 1e-6 it rejects, its t, u, v are
-//     rounding residue divided by that, and the hit it accepts lies up to a dozen margins outside the triangle's box
-//     (347 of 10^9 such rays on a 19 058-triangle model).  Option "traversal" = 1 keeps the unculled per-lane walk.
+//     missed by the ray would fail the reference's own test on the (smaller) real box: exact.  Two more skips need the
+//     reference's computed hit point o + t*d of a triangle it accepts to lie inside the triangle's box grown by that much:
+//     a LEAF whose grown box the ray misses, and ANY slot whose grown box begins beyond the best hit so far.
+//   * The guard: when that holds.  Triangle::intersect (orion/geometry.hpp:96-124) computes det = e1 . (d x e2) and
+//     t, u, v as three numerators over det, in FP32 (eps = 2^-24) with |error of a cross product| <= 3.2 eps |a||b| (one
+//     product rounded, one fused) and |error of a dot product| <= 3 eps |a||b|.  So |det - D| <= 6.5 eps |d||e1||e2| for the
+//     exact D = d . (e1 x e2), and each numerator is within 7.2 eps |o - v0| (times the other two lengths) of its exact value.
+//     If |D| >= kappa |d||e1||e2| (WELL CONDITIONED, kappa = kGuardKappa = 2^-11): the error of det scales all three quotients
+//     alike, which moves the point o + t*d against v0 + u*e1 + v*e2 by at most (6.5 eps / kappa) |o - v0|; the numerators'
+//     errors move it along e1, e2 and d by at most (7.2 eps / kappa) |o - v0| each: 28.1 eps |o - v0| / kappa in all.
+//     v0 + u*e1 + v*e2 is a point of the triangle (the accepted u, v, u + v lie in [0, 1]) and |o - v0| <= sqrt(3) (reach + pad),
+//     so the computed hit lies within 48.7 eps / kappa = 0.0059 of (reach + pad) of the triangle's box: 0.76 of the slack
+//     (tools/ab/guard_bound.py: the largest ratio seen on 5 * 10^6 accepted pairs near the threshold is 2.7 of the 28.1).
+//     The rest of the slack covers the rounding of the slot test itself (a few 10^-4 of it).  Both skips are then sound: the
+//     ray meets the triangle's grown box at the computed t.
+//     If |D| < kappa |d||e1||e2| (ILL CONDITIONED: the ray lies within asin(kappa / sin(apex)), about 0.03 degrees, of the
+//     triangle's plane) nothing bounds t, u, v: they are rounding residue over a tiny determinant, and the reference accepts
+//     them one time in ten -- UNLESS |d||e1||e2| <= kGuardHarmless = 2.0e-3, for then |det| <= (kappa + 6.5 eps) |d||e1||e2| <
+//     1e-6 and the reference itself rejects the triangle (orion/geometry.hpp:103).
+//     Every slot therefore carries a cone around the normals of the triangles below it (WideNode::guard, built by
+//     wide_bvh.h: guard_word): a slot is DANGEROUS for a ray if the cone admits a triangle that is ill conditioned for its
+//     direction.  A dangerous leaf is visited whatever its box says, as in the reference; a dangerous inner slot iff the ray
+//     meets its grown box anywhere (if not, the reference's test of that node's own box fails too); and neither is ever
+//     dropped for beginning beyond the best hit.  Rays no longer than kGuardHarmless / (the scene's largest |e1||e2|) need
+//     no guard.  With that, every triangle the reference accepts is either tested here or provably cannot beat the result.
+//     What it costs: the cone of a handful of bumpy triangles is wide (nanosuit: a leaf of four is dangerous for 42 % of all
+//     directions, a subtree of 64 for 94 %), so on scenes of large triangles a ray that crosses the model visits 3.3 times
+//     the nodes of the unguarded walk, a bounce ray 1.25 times (oracle/wide_model.cpp; a scene of small triangles, none).
+//     Option "wide_guard" = 0 switches the guard off: the walk then differs from the reference on rays aimed ALONG a
+//     triangle's plane at a slope below 1e-5 (349 of 2^30 such rays on a 19 058-triangle model, none of 1.6 * 10^10 natural
+//     rays: tools/ab/stress_wide.py).
 //   * Rays the argument does not cover -- an origin component that is not finite or beyond the scene's
 //     bound, a direction component that is zero, denormal, not finite or outside 2^-40 .. 2^40 -- and
 //     lanes whose stack would overflow take the unculled walk (traverse_lane) instead.
