@@ -178,7 +178,7 @@ constexpr uint32_t kWorkParts = 16, kWorkCounters = 64, kWorkWords = kWorkCounte
 constexpr uint32_t kCoherentChunks = ORION_COHERENT_CHUNKS;                // 64-ray chunks per block of k_query_coherent
 
 #ifndef ORION_DRAW_WAVES
-#define ORION_DRAW_WAVES 0
+#define ORION_DRAW_WAVES 6      // (with the guard's words the compiler's own choice is 87 registers and 5 waves: 6 waves with 2 spilled registers run 2 to 8 % faster)
 #endif
 #if ORION_DRAW_WAVES
 #define ORION_DRAW_ATTR __attribute__((amdgpu_waves_per_eu(ORION_DRAW_WAVES, ORION_DRAW_WAVES)))
@@ -248,12 +248,6 @@ constexpr uint32_t kNoOwner = 64u;
 constexpr uint32_t kShareMin = ORION_SHARE_MIN;      // free lanes it takes to make a round of handing out worthwhile
 static_assert(kWideStack >= 13, "a handed-over part travels through the taker's (empty) stack column: 13 words");
 __shared__ uint8_t g_wide_taker[kWideBlock];
-
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Free lanes take parts from lanes that have something stacked.  Returns whether free lanes remain or were
 // served (the caller then gives the busy lanes a chance to stack something after every node step).
@@ -443,14 +437,13 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
         }
         // Node steps until nobody is at a node -- or until enough lanes wait at a leaf, or enough have run
         // out of work to make fetching worthwhile: they would sit idle while the others walk on.
-        const bool guard = __any(w.cur != kWideEmpty && guard_words.dp != 0u);
         for (;;) {
             const bool at_node = wide_at_node(w);
             if (!__any(at_node)) break;
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kLeafQuorumWide) break;
             if (!pool_empty && (uint32_t)__popcll(__ballot(w.cur == kWideEmpty && !slow)) >= kRefillMin) break;
             WIDE_STAT(1, 1u); WIDE_STAT(2, (uint32_t)__popcll(__ballot(at_node)));
-            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, guard_words, guard);
+            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, guard_words);
             if (__any(over)) {   // a stack that is full: that node's subtree goes to the unculled walk
                 if (over && !wide_overflow<ANY>(S, o, d, inv, false, h, w, tid)) slow = true;
             }

@@ -101,21 +101,6 @@ __device__ __forceinline__ float vmax3_abs(float a, float b, float c) { float r;
 // (the lower bounds if it runs up the axis, the upper bounds if it runs down) and where it leaves them.
 struct WideBytes { uint32_t nx, ny, nz, fx, fy, fz; };
 
-// Slot K's entry distance, or +inf if the slot is empty, missed, behind the origin or beyond
-// `best`.  The slab distances of the grown box come straight from the bytes: byte * c + l where the ray enters the slab,
-// byte * c + u where it leaves it (wide_node_step computes c, l, u per axis).
-template <int K>
-__device__ __forceinline__ float wide_slot(const WideBytes& q, V3 c, V3 l, V3 u, float best, uint32_t ref) {
-    const float t1x = fmaf(byte_of<K>(q.nx), c.x, l.x), t2x = fmaf(byte_of<K>(q.fx), c.x, u.x);
-    const float t1y = fmaf(byte_of<K>(q.ny), c.y, l.y), t2y = fmaf(byte_of<K>(q.fy), c.y, u.y);
-    const float t1z = fmaf(byte_of<K>(q.nz), c.z, l.z), t2z = fmaf(byte_of<K>(q.fz), c.z, u.z);
-    // "tmax >= tmin, tmax >= 0, tmin <= best" with best >= 0 is "max(tmin, 0) <= min(tmax, best)"
-    const float tmin = vmax3(t1x, t1y, t1z);
-    const float tmax = vmin(vmin3(t2x, t2y, t2z), best);
-    const bool hit = (ref != kWideEmpty) & (vmax(tmin, 0.0f) <= tmax);   // (&: no branch around the comparison)
-    return hit ? tmin : __builtin_inff();   // (a negative tmin orders the slots that hold the origin)
-}
-
 // The guard (see the header comment): the ray's direction as two words of signed bytes, D = d^ * 127 rounded, in the
 // forms (Dx, Dy, Dz, -127) and (-Dx, -Dy, -Dz, -127).  A slot's guard word is (Ax, Ay, Az, c) (wide_bvh.h: guard_word), so the two
 // byte-wise dot products are A . D - 127 c and -(A . D) - 127 c: both negative iff |A . D| < 127 c, the slot may then
@@ -142,8 +127,10 @@ __device__ __forceinline__ bool wide_danger(uint32_t word, WideGuard g) {
     return max(a, b) < 0;
 }
 
-// Slot K with the guard: `vis` = the slot is to be visited, `keep` = it may not be dropped later however near the best hit
-// has come by then (it goes onto the stack with distance 0).  A slot that is not dangerous is skipped as in wide_slot.  A
+// Slot K: its entry distance, or +inf if it is not to be visited; `keep` = it may not be dropped later however near the
+// best hit has come by then (it goes onto the stack with distance 0).  The slab distances of the grown box come straight
+// from the bytes: byte * c + l where the ray enters the slab, byte * c + u where it leaves it (wide_node_step computes
+// c, l, u per axis).  A slot that is not dangerous is skipped when it is empty, missed, behind the origin or beyond `best`.  A
 // dangerous inner slot is visited iff the ray meets its grown box at all, however far away (if it does not, the
 // reference's own test of the inner node's box fails too); a dangerous leaf is visited whatever its box says, as in the
 // reference.  Slots visited only because they are dangerous come after the others (distance kWideLast).
@@ -166,11 +153,11 @@ __device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 
 
 // One wide node: the reference's test on its own box, then the four slots; the nearest one is next and the
 // others go onto the stack.  Returns false, with the lane still at the node, if the stack would overflow
-// (wide_overflow then deals with the node's subtree).  `guard`: wave-uniform, whether any lane's ray needs the guard.
-__device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid, WideGuard g, bool guard) {
+// (wide_overflow then deals with the node's subtree).
+__device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid, WideGuard g) {
     const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
-    float4 A = np[0], B = np[1], C = np[2], D = np[3];
-    pin(A); pin(B); pin(C); pin(D);
+    float4 A = np[0], B = np[1], C = np[2], D = np[3], G = np[4];
+    pin(A); pin(B); pin(C); pin(D); pin(G);
     const float inf = __builtin_inff();
     float t0 = inf, t1 = inf, t2 = inf, t3 = inf;
     bool k0 = false, k1 = false, k2 = false, k3 = false;
@@ -197,19 +184,11 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
         const uint32_t lx = __float_as_uint(C.x), ly = __float_as_uint(C.y), lz = __float_as_uint(C.z);
         const uint32_t hx = __float_as_uint(C.w), hy = __float_as_uint(D.x), hz = __float_as_uint(D.y);
         const WideBytes q = {ux ? lx : hx, uy ? ly : hy, uz ? lz : hz, ux ? hx : lx, uy ? hy : ly, uz ? hz : lz};
-        if (guard) {
-            float4 G = np[4];
-            pin(G);
-            t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, __float_as_uint(G.x), g, k0);
-            t1 = wide_slot_guarded<1>(q, c, l, u, best, r1, __float_as_uint(G.y), g, k1);
-            t2 = wide_slot_guarded<2>(q, c, l, u, best, r2, __float_as_uint(G.z), g, k2);
-            t3 = wide_slot_guarded<3>(q, c, l, u, best, r3, __float_as_uint(G.w), g, k3);
-        } else {
-            t0 = wide_slot<0>(q, c, l, u, best, r0);
-            t1 = wide_slot<1>(q, c, l, u, best, r1);
-            t2 = wide_slot<2>(q, c, l, u, best, r2);
-            t3 = wide_slot<3>(q, c, l, u, best, r3);
-        }
+        // (one form of the slot test for every ray: a ray that needs no guard carries zero words, for which no slot is dangerous)
+        t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, __float_as_uint(G.x), g, k0);
+        t1 = wide_slot_guarded<1>(q, c, l, u, best, r1, __float_as_uint(G.y), g, k1);
+        t2 = wide_slot_guarded<2>(q, c, l, u, best, r2, __float_as_uint(G.z), g, k2);
+        t3 = wide_slot_guarded<3>(q, c, l, u, best, r3, __float_as_uint(G.w), g, k3);
     }
     const float tn = vmin(vmin3(t0, t1, t2), t3);
     if (!(tn < inf)) { wide_pop(w, best, tid); return true; }
@@ -249,6 +228,12 @@ __device__ __forceinline__ bool wide_leaf_step(const SceneView& S, V3 o, V3 d, H
     }
     wide_pop(w, h.t, tid);
     return false;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // A lane whose stack cannot take a node's slots (`over`: wide_node_step returned false; trees deeper than the
@@ -296,7 +281,6 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
     WideState w; w.cur = 0u; w.sp = 0u; w.best_slot = 0u;
     bool ok = true;
     const WideGuard g = wide_guard_of(S, d);
-    const bool guard = __any(g.dp != 0u);
     // The lanes of the wave that walk do so together: node steps until nobody is at a node or kStaticQuorum lanes
     // wait at a leaf (they would idle while the others walk on), then the leaves (nanosuit frame with four
     // bounces: +13 % against "every lane to its next leaf first"; 8, 12 and 16 lanes within 2 % of each other).
@@ -306,7 +290,7 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
             const bool at_node = wide_at_node(w);
             if (!__any(at_node)) break;
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kStaticQuorum) break;
-            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, g, guard);
+            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, g);
             if (__any(over)) {
                 if (over) ok = wide_overflow<ANY>(S, o, d, inv, false, h, w, tid) && ok;
             }
