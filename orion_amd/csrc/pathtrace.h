@@ -437,13 +437,14 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
         }
         // Node steps until nobody is at a node -- or until enough lanes wait at a leaf, or enough have run
         // out of work to make fetching worthwhile: they would sit idle while the others walk on.
+        const bool guard = __any(w.cur != kWideEmpty && guard_words.dp != 0u);
         for (;;) {
             const bool at_node = wide_at_node(w);
             if (!__any(at_node)) break;
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kLeafQuorumWide) break;
             if (!pool_empty && (uint32_t)__popcll(__ballot(w.cur == kWideEmpty && !slow)) >= kRefillMin) break;
             WIDE_STAT(1, 1u); WIDE_STAT(2, (uint32_t)__popcll(__ballot(at_node)));
-            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, guard_words);
+            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, guard_words, guard);
             if (__any(over)) {   // a stack that is full: that node's subtree goes to the unculled walk
                 if (over && !wide_overflow<ANY>(S, o, d, inv, false, h, w, tid)) slow = true;
             }

@@ -123,7 +123,10 @@ __device__ __forceinline__ WideGuard wide_guard_of(const SceneView& S, V3 d) {
 }
 
 __device__ __forceinline__ bool wide_danger(uint32_t word, WideGuard g) {
-    const int a = __builtin_amdgcn_sdot4((int)word, (int)g.dp, 0, false), b = __builtin_amdgcn_sdot4((int)word, (int)g.dm, 0, false);
+    // (the three-operand form with a zero accumulator: the builtin picks the accumulating form and a move to clear it)
+    int a, b;
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(a) : "v"(word), "v"(g.dp));
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(b) : "v"(word), "v"(g.dm));
     return max(a, b) < 0;
 }
 
@@ -136,7 +139,7 @@ __device__ __forceinline__ bool wide_danger(uint32_t word, WideGuard g) {
 // reference.  Slots visited only because they are dangerous come after the others (distance kWideLast).
 constexpr float kWideLast = 3.0e38f;
 template <int K>
-__device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 l, V3 u, float best, uint32_t ref, uint32_t word, WideGuard g, bool& keep) {
+__device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 l, V3 u, float best, uint32_t ref, bool danger, bool& keep) {
     const float t1x = fmaf(byte_of<K>(q.nx), c.x, l.x), t2x = fmaf(byte_of<K>(q.fx), c.x, u.x);
     const float t1y = fmaf(byte_of<K>(q.ny), c.y, l.y), t2y = fmaf(byte_of<K>(q.fy), c.y, u.y);
     const float t1z = fmaf(byte_of<K>(q.nz), c.z, l.z), t2z = fmaf(byte_of<K>(q.fz), c.z, u.z);
@@ -144,7 +147,6 @@ __device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 
     const float tmax = vmin3(t2x, t2y, t2z);
     const bool met = vmax(tmin, 0.0f) <= tmax;            // the ray meets the grown box somewhere
     const bool within = met & (tmin <= best);
-    const bool danger = wide_danger(word, g);
     const bool leaf = (ref & kWideLeaf) != 0u;
     keep = danger;
     const bool vis = (ref != kWideEmpty) & (within | (danger & (met | leaf)));
@@ -153,11 +155,11 @@ __device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 
 
 // One wide node: the reference's test on its own box, then the four slots; the nearest one is next and the
 // others go onto the stack.  Returns false, with the lane still at the node, if the stack would overflow
-// (wide_overflow then deals with the node's subtree).
-__device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid, WideGuard g) {
+// (wide_overflow then deals with the node's subtree).  `guard`: wave-uniform, whether any lane's ray needs the guard.
+__device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid, WideGuard g, bool guard) {
     const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
-    float4 A = np[0], B = np[1], C = np[2], D = np[3], G = np[4];
-    pin(A); pin(B); pin(C); pin(D); pin(G);
+    float4 A = np[0], B = np[1], C = np[2], D = np[3];
+    pin(A); pin(B); pin(C); pin(D);
     const float inf = __builtin_inff();
     float t0 = inf, t1 = inf, t2 = inf, t3 = inf;
     bool k0 = false, k1 = false, k2 = false, k3 = false;
@@ -184,11 +186,20 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
         const uint32_t lx = __float_as_uint(C.x), ly = __float_as_uint(C.y), lz = __float_as_uint(C.z);
         const uint32_t hx = __float_as_uint(C.w), hy = __float_as_uint(D.x), hz = __float_as_uint(D.y);
         const WideBytes q = {ux ? lx : hx, uy ? ly : hy, uz ? lz : hz, ux ? hx : lx, uy ? hy : ly, uz ? hz : lz};
-        // (one form of the slot test for every ray: a ray that needs no guard carries zero words, for which no slot is dangerous)
-        t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, __float_as_uint(G.x), g, k0);
-        t1 = wide_slot_guarded<1>(q, c, l, u, best, r1, __float_as_uint(G.y), g, k1);
-        t2 = wide_slot_guarded<2>(q, c, l, u, best, r2, __float_as_uint(G.z), g, k2);
-        t3 = wide_slot_guarded<3>(q, c, l, u, best, r3, __float_as_uint(G.w), g, k3);
+        // Which slots are dangerous: only in waves that hold a ray that needs the guard (the others skip the node's fifth
+        // load and these instructions; a ray that needs none carries zero words, for which no slot is dangerous).  The slot
+        // test itself has one form.
+        bool d0 = false, d1 = false, d2 = false, d3 = false;
+        if (guard) {
+            float4 G = np[4];
+            pin(G);
+            d0 = wide_danger(__float_as_uint(G.x), g); d1 = wide_danger(__float_as_uint(G.y), g);
+            d2 = wide_danger(__float_as_uint(G.z), g); d3 = wide_danger(__float_as_uint(G.w), g);
+        }
+        t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, d0, k0);
+        t1 = wide_slot_guarded<1>(q, c, l, u, best, r1, d1, k1);
+        t2 = wide_slot_guarded<2>(q, c, l, u, best, r2, d2, k2);
+        t3 = wide_slot_guarded<3>(q, c, l, u, best, r3, d3, k3);
     }
     const float tn = vmin(vmin3(t0, t1, t2), t3);
     if (!(tn < inf)) { wide_pop(w, best, tid); return true; }
@@ -281,6 +292,7 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
     WideState w; w.cur = 0u; w.sp = 0u; w.best_slot = 0u;
     bool ok = true;
     const WideGuard g = wide_guard_of(S, d);
+    const bool guard = __any(g.dp != 0u);
     // The lanes of the wave that walk do so together: node steps until nobody is at a node or kStaticQuorum lanes
     // wait at a leaf (they would idle while the others walk on), then the leaves (nanosuit frame with four
     // bounces: +13 % against "every lane to its next leaf first"; 8, 12 and 16 lanes within 2 % of each other).
@@ -290,7 +302,7 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
             const bool at_node = wide_at_node(w);
             if (!__any(at_node)) break;
             if ((uint32_t)__popcll(__ballot(wide_at_leaf(w))) >= kStaticQuorum) break;
-            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, g);
+            const bool over = at_node && !wide_node_step(S, o, inv, h.t, w, tid, g, guard);
             if (__any(over)) {
                 if (over) ok = wide_overflow<ANY>(S, o, d, inv, false, h, w, tid) && ok;
             }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lane occupancy of the ray-drawing wide walk (k_query_wide) on the ray-bench batches, from a build of the
-library with -DORION_WIDE_STATS=1 (ORION_HIP_LIB points at it).  Usage: wide_stats.py [scene ...]"""
+library with -DORION_WIDE_STATS=1 (ORION_HIP_LIB points at it).  Usage: wide_stats.py [scene ...]   WIDE_GUARD=0: without the walk's guard"""
 import ctypes
 import os
 import sys
@@ -23,6 +23,8 @@ def main():
         model = conftest.load_model(name)
         sc = api.Scene(model, device=0)
         sc.set_option("traversal", 4)
+        if os.environ.get("WIDE_GUARD"):
+            sc.set_option("wide_guard", int(os.environ["WIDE_GUARD"]))
         eye, look, up, yv = raygen.default_camera(model)
         cam = api.camera_vectors(eye, look, up, yv, 16 / 9)
         o1, d1 = raygen.primary_rays(cam, 1920, 1080, n, seed=1)
