@@ -223,8 +223,8 @@ class WideModel:
             self.h = None
 
     def nodes(self):
-        """(n_nodes x 20 words as uploaded, n_nodes x 4 triangle counts below each slot)."""
-        words = np.zeros((self.n_nodes, 20), np.uint32); below = np.zeros((self.n_nodes, 4), np.uint32)
+        """(n_nodes x 16 words as uploaded, n_nodes x 4 triangle counts below each slot)."""
+        words = np.zeros((self.n_nodes, 16), np.uint32); below = np.zeros((self.n_nodes, 4), np.uint32)
         oracle_lib().wide_model_nodes(C.c_void_p(self.h), _p(words), _p(below))
         return words, below
 

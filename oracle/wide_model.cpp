@@ -9,8 +9,11 @@
 // code fuses (cross), dot = (p0 + p1) + (p2 + 0.0f).
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include <omp.h>
@@ -44,7 +47,38 @@ struct Model {
     std::vector<uint32_t> tri_mesh, mesh_base;
     orion_wide::WideTree tree;
     std::vector<std::vector<uint32_t>> below;   // 4 per wide node: triangle slots below (mode 3, the ideal certificate; built on first use)
+    // The guard's table (orion_amd/csrc/wide_guard.h), one row per direction cell, built when a ray first asks for the cell:
+    // per node four bits, "slot k may hold a triangle that is ill conditioned for some direction of the cell".
+    uint32_t grid = 0;
+    std::mutex mu;
+    std::unordered_map<uint32_t, std::vector<uint8_t>> rows;
 };
+
+const uint8_t* cell_row(Model& M, uint32_t cell) {
+    std::lock_guard<std::mutex> lock(M.mu);
+    auto it = M.rows.find(cell);
+    if (it != M.rows.end()) return it->second.data();
+    float c[3], sr, cr;
+    orion_dev::guard_cell_geometry(M.grid, cell, c, sr, cr);
+    std::vector<uint8_t> row(M.tree.nodes.size(), 0);
+    for (size_t i = M.tree.nodes.size(); i-- > 0;) {      // children stand behind their parents
+        const WideNode& n = M.tree.nodes[i];
+        const uint32_t refs[4] = {n.ref0, n.ref1, n.ref2, n.ref3};
+        uint8_t bits = 0;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t ref = refs[k];
+            if (ref == orion_dev::kWideEmpty) continue;
+            bool a = false;
+            if (ref & 0x80000000u) {
+                const uint32_t first = ref & 0x1FFFFFFu, count = (ref >> 25) & 63u;
+                for (uint32_t s = first; s < first + count && !a; s++) a = orion_dev::guard_band_meets_cell(M.tree.bands[s], c, sr, cr);
+            } else a = row[ref] != 0;
+            if (a) bits |= (uint8_t)(1u << k);
+        }
+        row[i] = bits;
+    }
+    return M.rows.emplace(cell, std::move(row)).first->second.data();
+}
 
 struct Stats {
     uint64_t nodes = 0, own_fail = 0, leaves = 0, tris = 0, stale = 0, candidates = 0, danger_visits = 0, danger_slots = 0, slots_seen = 0;
@@ -83,34 +117,23 @@ inline bool tame(const Model& M, V3 o, V3 d) {
 
 // cull = false: every slot the reference's rule allows is visited (the decoded boxes are ignored), which is
 // the reference's candidate set; used to measure the excess.  Returns false for a ray the walk does not take.
-// The guard of the product's walk (orion_amd/csrc/wide_walk.h: wide_guard_of, wide_danger): the direction as signed
-// bytes of length 127, a slot's cone word (wide_bvh.h: guard_word), "dangerous" iff |A . D| < 127 c.
-struct GuardDir { int x, y, z; bool on; };
-inline GuardDir guard_dir(const Model& M, V3 d) {
-    GuardDir g = {0, 0, 0, false};
+// The guard of the product's walk (orion_amd/csrc/wide_walk.h: wide_guard_of): the cell of the ray's direction, or none
+// for a ray too short for any triangle of the scene to pass the reference's determinant test ill conditioned.
+inline uint32_t guard_cell(const Model& M, V3 d) {
     const float l2 = fmaf(d.x, d.x, fmaf(d.y, d.y, d.z * d.z));
-    if (!(l2 * 1.00001f <= M.tree.guard_dlen * M.tree.guard_dlen)) {
-        const float r = 127.0f * (1.0f / std::sqrt(l2));
-        auto q = [&](float v) { const int i = (int)std::lrintf(v * r); return std::max(-127, std::min(127, i)); };
-        g.x = q(d.x); g.y = q(d.y); g.z = q(d.z); g.on = true;
-    }
-    return g;
-}
-inline bool guard_danger(uint32_t word, const GuardDir& g) {
-    if (!g.on) return false;
-    const int ax = (int8_t)(word & 0xFFu), ay = (int8_t)((word >> 8) & 0xFFu), az = (int8_t)((word >> 16) & 0xFFu), c = (int8_t)(word >> 24);
-    const int dot = ax * g.x + ay * g.y + az * g.z;
-    return std::max(dot - 127 * c, -dot - 127 * c) < 0;
+    if (l2 * 1.00001f <= M.tree.guard_dlen * M.tree.guard_dlen) return orion_dev::kGuardNoCell;
+    return orion_dev::guard_cell_of(d.x, d.y, d.z, M.grid);
 }
 
-bool walk(const Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& st) {
+bool walk(Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& st) {
     if (!tame(M, o, d)) { st.untame++; return false; }
     const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float pad = M.tree.pad;
     best.t = std::numeric_limits<float>::infinity(); best.u = best.v = 0.0f; best.slot = 0xFFFFFFFFu;
     struct Entry { uint32_t ref; float tmin; bool danger; float cull_t; };
     std::vector<Entry> stack;
-    const GuardDir gd = guard_dir(M, d);
+    const uint32_t gcell = cull == 2 ? guard_cell(M, d) : orion_dev::kGuardNoCell;
+    const uint8_t* grow = gcell != orion_dev::kGuardNoCell ? cell_row(M, gcell) : nullptr;
     const double dlen = std::sqrt((double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z);
     uint32_t cur = 0;           // node index, or 0x80000000 | count << 25 | first triangle slot
     uint32_t my_depth = 0, my_steps = 0;
@@ -145,7 +168,7 @@ bool walk(const Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& 
                     const bool within = met && (a <= best.t);
                     bool danger = false;
                     st.slots_seen++;
-                    if (cull == 2) danger = guard_danger(n.guard[k], gd);
+                    if (cull == 2 && grow) danger = ((grow[cur] >> k) & 1u) != 0u;
                     if (cull == 3) {   // the ideal certificate: is any triangle below ill conditioned for this ray and large enough to be accepted?
                         for (uint32_t s : M.below[4 * cur + k]) {
                             const Tri& T = M.tris[s];
@@ -153,7 +176,10 @@ bool walk(const Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& 
                             const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
                             const double m = std::sqrt((e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) * (e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]));
                             if (dlen * m <= (double)orion_dev::kGuardHarmless) continue;
-                            if (std::fabs(c[0] * d.x + c[1] * d.y + c[2] * d.z) < (double)orion_dev::kGuardKappa * dlen * m) { danger = true; break; }
+                            static const double rho = std::getenv("WIDE_MODEL_CELL_DEG") ? std::atof(std::getenv("WIDE_MODEL_CELL_DEG")) * 3.14159265358979 / 180.0 : 0.0;   // a direction cell's radius
+                            const double lc = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+                            const double beta = std::asin(std::fmin(1.0, (double)orion_dev::kGuardKappa * m / std::fmax(lc, 1e-300)));
+                            if (std::fabs(c[0] * d.x + c[1] * d.y + c[2] * d.z) < std::sin(std::fmin(1.5707963, beta + rho)) * dlen * lc) { danger = true; break; }
                         }
                     }
                     // a dangerous inner slot the ray's line misses fails the reference's own box test; a dangerous leaf is visited anyway
@@ -260,6 +286,8 @@ void* wide_model_create(const OrionMeshDesc* meshes, uint32_t n_meshes, char* wh
         tri_base += ntri;
     }
     M->tree = orion_wide::build_wide_tree(meshes, n_meshes, slot_base, M->tris);
+    M->grid = orion_dev::guard_grid_for(M->tree.nodes.size());
+    if (const char* e = std::getenv("ORION_HIP_GUARD_GRID")) { const int g = std::atoi(e); if (g == 32 || g == 64 || g == 128 || g == 256) M->grid = (uint32_t)g; }
     if (M->tree.nodes.empty()) {
         if (why) { std::strncpy(why, M->tree.why_not.c_str(), 255); why[255] = 0; }
         delete M;
@@ -277,7 +305,7 @@ void wide_model_info(void* h, uint32_t* info, float* finfo) {
     finfo[0] = M->tree.pad; finfo[1] = M->tree.org_bound;
 }
 
-// The tree's nodes as they are uploaded (n_nodes x 20 words), and per node and slot the number of triangles below.
+// The tree's nodes as they are uploaded (n_nodes x 16 words), and per node and slot the number of triangles below.
 void wide_model_nodes(void* h, uint32_t* words, uint32_t* below4) {
     Model* M = static_cast<Model*>(h);
     std::memcpy(words, M->tree.nodes.data(), M->tree.nodes.size() * sizeof(WideNode));

@@ -64,8 +64,8 @@ struct WaveItem {
 };
 static_assert(sizeof(WaveItem) == 64, "WaveItem layout");
 
-// One node of the 4-wide tree the ordered, distance-culled walk of large scenes uses (80 bytes,
-// five 16-byte loads).  It is a collapse of the reference's binary trees that keeps the reference's
+// One node of the 4-wide tree the ordered, distance-culled walk of large scenes uses (64 bytes,
+// four 16-byte loads).  It is a collapse of the reference's binary trees that keeps the reference's
 // visit rule: a triangle counts iff every binary inner node above it passes AABB::intersect
 // (orion/avx/sbvh.cpp:36-83, orion/AABB.hpp:79-99).
 //   * `lo`/`hi` is the exact box of the binary inner node this wide node stands for; the walk
@@ -79,10 +79,6 @@ static_assert(sizeof(WaveItem) == 64, "WaveItem layout");
 //     three quarters of the pad.  These boxes only ever REJECT: a slot is skipped when the ray misses
 //     its decoded box (grown by the pad and the walk's slack) or meets it beyond the best hit so far.
 //   * ref: kWideEmpty, the index of a wide node, or kWideLeaf | count << 25 | first triangle slot.
-//   * guard: per slot, a cone around the normals of every triangle below it (wide_bvh.h: WideGuard).  Two of the
-//     walk's skips (a leaf whose box is missed, anything that begins beyond the best hit) are only sound for
-//     triangles whose test is well conditioned for the ray; the cone tells the walk when a slot may hold one
-//     that is not, and such a slot is then visited whatever its box says (wide_walk.h).
 // Virtual nodes tie the meshes' roots together; their box is the union of what hangs below, grown
 // by more than any slack the walk applies, so that missing it means missing everything below.
 struct WideNode {
@@ -91,9 +87,8 @@ struct WideNode {
     uint32_t qlo[3];        // per axis: the four slots' lower bounds, one byte each (slot 0 in bits 0-7)
     uint32_t qhi[3];
     uint32_t ref2, ref3;
-    uint32_t guard[4];      // per slot: cone axis as three signed bytes (x in bits 0-7) and the cone's code in bits 24-30
 };
-static_assert(sizeof(WideNode) == 80, "WideNode layout");
+static_assert(sizeof(WideNode) == 64, "WideNode layout");
 constexpr uint32_t kWideEmpty = 0x7FFFFFFFu;   // also "nothing left to visit" in the walk
 constexpr uint32_t kWideLeaf = 0x80000000u;
 constexpr uint32_t kWideMaxLeaf = 63;
@@ -107,8 +102,6 @@ constexpr float kWideInvCells = 1.0f / 254.0f;   // one cell of the byte grid, a
 // determinant then falls below the 1e-6 the reference rejects (orion/geometry.hpp:103).
 constexpr float kGuardKappa = 0x1p-11f;
 constexpr float kGuardHarmless = 2.0e-3f;
-constexpr int kGuardAxisScale = 110;     // length of the quantised cone axis
-constexpr int kGuardAlways = 127;        // cone code of a slot that is dangerous for every direction
 
 struct Texture {
     uint32_t offset;   // element offset into texels_f32 (floats) or texels_u8 (bytes)
@@ -169,10 +162,14 @@ struct SceneView {
     float wide_pad;          // every decoded slot box, grown by this, contains its real box (wide_bvh.h)
     float wide_grow0;        // wide_pad * (1 + 2 * kWideSlack): what a slot box is grown by before the distance term
     float wide_org_bound;    // rays with an origin component beyond this take the unculled walk
-    // The guard of the walk's unproven skips (WideNode::guard): on unless the caller switched it off (0), and only
+    // The guard of the walk's unproven skips (wide_walk.h): on unless the caller switched it off (0), and only
     // for rays longer than wide_guard_dlen = kGuardHarmless / (the largest |e1| |e2| of the scene's triangles).
+    // wide_cells: per wide node a row of wide_cells_row bytes, four bits per cell of the wide_cells_grid^2 grid over
+    // the ray directions (wide_guard.h): bit k = slot k may hold a triangle that is ill conditioned for a direction of the cell.
     uint32_t wide_guard;
     float wide_guard_dlen;
+    const uint8_t* wide_cells;
+    uint32_t wide_cells_grid, wide_cells_row;
 };
 
 // Closest-hit record kept in the queues: 16 bytes.  gtri == kInvalid is a miss.

@@ -357,7 +357,7 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
     HitRec h = miss_rec();
     WideState w; w.cur = kWideEmpty; w.sp = 0u; w.best_slot = 0u;
     bool quick_det = false, slow = false;
-    WideGuard guard_words; guard_words.dp = 0u; guard_words.dm = 0u;
+    WideGuard guard_words; guard_words.cell = kGuardNoCell;
     // Sharing (see wide_share): the lane whose ray this lane walks a part of, and how many lanes walk parts of this lane's.
     uint32_t owner = kNoOwner, lent = 0u;
 #if ORION_WIDE_STATS
@@ -437,7 +437,7 @@ __device__ __forceinline__ void wide_draw_rays(const SceneView& S, uint32_t n, u
         }
         // Node steps until nobody is at a node -- or until enough lanes wait at a leaf, or enough have run
         // out of work to make fetching worthwhile: they would sit idle while the others walk on.
-        const bool guard = __any(w.cur != kWideEmpty && guard_words.dp != 0u);
+        const bool guard = __any(w.cur != kWideEmpty && guard_words.cell != kGuardNoCell);
         for (;;) {
             const bool at_node = wide_at_node(w);
             if (!__any(at_node)) break;
@@ -487,6 +487,44 @@ __global__ __launch_bounds__(kBlock) ORION_DRAW_ATTR void k_query_wide(SceneView
     wide_draw_rays<ANY, LISTED>(S, n, grab, work, chunks,
                                 [&](uint32_t i, V3& o, V3& d) { o = ld3(org + 3ull * i); d = ld3(dir + 3ull * i); },
                                 [&](uint32_t i, const HitRec& h) { query_store<ANY>(S, i, h, out, occ); });
+}
+
+// --- the wide walk's guard table -------------------------------------------------
+// Four bits per node and direction cell (wide_guard.h), two cells to a byte: one thread per byte of a node's row walks the
+// node array from the back -- a node's children stand behind it, so an inner slot's bit is "the child's four bits are not all
+// zero", read from the row this thread wrote earlier -- and tests a leaf slot's triangles against its two cells.  The node
+// and band records are the same for all threads at any moment (scalar loads), the table's bytes coalesce.
+__global__ __launch_bounds__(kBlock) void k_guard_cells(const WideNode* __restrict__ nodes, uint32_t n_nodes, const GuardBand* __restrict__ bands,
+                                                        uint32_t G, uint8_t* table, uint32_t row) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= row) return;
+    float ca[3], cb[3], sa, ka, sb, kb;
+    guard_cell_geometry(G, 2u * t, ca, sa, ka);
+    guard_cell_geometry(G, 2u * t + 1u, cb, sb, kb);
+    for (uint32_t i = n_nodes; i-- > 0u;) {
+        const WideNode n = nodes[i];
+        const uint32_t refs[4] = {n.ref0, n.ref1, n.ref2, n.ref3};
+        uint32_t byte = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t ref = refs[k];
+            if (ref == kWideEmpty) continue;
+            bool a = false, b = false;
+            if (ref & kWideLeaf) {
+                const uint32_t first = ref & 0x01FFFFFFu, count = (ref >> 25) & 63u;
+                for (uint32_t s2 = 0; s2 < count; s2++) {
+                    const GuardBand band = bands[first + s2];
+                    a = a || guard_band_meets_cell(band, ca, sa, ka);
+                    b = b || guard_band_meets_cell(band, cb, sb, kb);
+                }
+            } else {
+                const uint32_t child = table[(size_t)ref * row + t];
+                a = (child & 0x0Fu) != 0u; b = (child & 0xF0u) != 0u;
+            }
+            byte |= (a ? 1u : 0u) << k | (b ? 1u : 0u) << (4u + k);
+        }
+        table[(size_t)i * row + t] = (uint8_t)byte;
+    }
 }
 
 // --- path tracing --------------------------------------------------------------

@@ -21,6 +21,7 @@
 
 #include "../../include/orion_hip.h"
 #include "device_types.h"
+#include "wide_guard.h"
 
 namespace orion_wide {
 
@@ -32,8 +33,7 @@ using orion_dev::kWideMaxLeaf;
 using orion_dev::kWideSlack;
 using orion_dev::kGuardKappa;
 using orion_dev::kGuardHarmless;
-using orion_dev::kGuardAxisScale;
-using orion_dev::kGuardAlways;
+using orion_dev::GuardBand;
 
 // The grid of a wide node along one axis: 254 cells from the lower to the upper bound of the node's own box
 // (byte 255 lies one cell beyond the upper bound).  The walk never decodes a byte into a coordinate: it places
@@ -47,6 +47,7 @@ struct WideTree {
     float org_bound = 0.0f;        // rays with an origin component beyond this take the unculled walk
     uint32_t stack_need = 0;       // deepest the ordered walk's stack can get
     float guard_dlen = 0.0f;       // rays whose direction is at most this long need no guard (no triangle is large enough)
+    std::vector<GuardBand> bands;  // per triangle slot: unit normal and the half-width of its band of ill-conditioned directions (wide_guard.h)
     std::string why_not;           // set when nodes is empty
 };
 
@@ -70,82 +71,6 @@ inline bool box_inside(const Box& in, const Box& out) {
 inline float box_half_area(const Box& b) {
     const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
     return dx * dy + dy * dz + dz * dx;
-}
-
-// The guard word of a set of triangles (WideNode::guard): a cone around their normals, as lines through the origin.
-// A triangle's test is ill conditioned for a direction d when |d^ . n^| < kGuardKappa / sin(apex), n^ its unit
-// normal, apex the angle between its edge vectors at v0 (that is |d . (e1 x e2)| < kGuardKappa |d| |e1| |e2|), which is a
-// band of half-width beta = asin(kGuardKappa / sin(apex)) around the great circle of directions perpendicular to n^.
-// With theta the angle between n^'s line and the cone's axis, no triangle of the set is ill conditioned for d if the
-// angle between d's line and the axis is at most 90 degrees - max(theta + beta): |d^ . axis^| >= sin(max(theta + beta)).
-// The word holds the axis A as three signed bytes (length about kGuardAxisScale) and the code
-// c = ceil(sin(max(theta + beta)) * |A| + what quantising d^ to signed bytes of length 127 can move A . D by);
-// the walk calls the set dangerous for d iff |A . D| < 127 c, D = d^ * 127 rounded to bytes (wide_walk.h).
-// c = kGuardAlways: dangerous whatever d (|A . D| < 127 * 127 always).
-inline uint32_t guard_word(const std::vector<Tri>& tris, const std::vector<uint32_t>& set) {
-    const uint32_t always = (uint32_t)kGuardAlways << 24;
-    if (set.empty()) return 0u;   // nothing below: never dangerous (A = 0, c = 0: |A . D| < 0 is false)
-    const size_t n = set.size();
-    std::vector<double> nn(3 * n), beta(n);
-    for (size_t j = 0; j < n; j++) {
-        const Tri& T = tris[set[j]];
-        const double e1[3] = {T.e1[0], T.e1[1], T.e1[2]}, e2[3] = {T.e2[0], T.e2[1], T.e2[2]};
-        double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-        const double m = std::sqrt((e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) * (e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]));
-        const double lc = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-        if (!(lc > 0.0) || !(m > 0.0) || !std::isfinite(lc) || !std::isfinite(m)) return always;   // no normal: every direction lies in its "plane"
-        const double sin_apex = lc / m;
-        if (!(sin_apex > 1.001 * (double)kGuardKappa)) return always;
-        beta[j] = std::asin(1.001 * (double)kGuardKappa / sin_apex);
-        for (int a = 0; a < 3; a++) nn[3 * j + a] = c[a] / lc;
-    }
-    // axis: the mean of the normals turned to one side, then moved a few times towards the line that is farthest off
-    double ax[3] = {nn[0], nn[1], nn[2]};
-    {
-        double sum[3] = {0, 0, 0};
-        for (size_t j = 0; j < n; j++) {
-            const double sgn = (ax[0] * nn[3 * j] + ax[1] * nn[3 * j + 1] + ax[2] * nn[3 * j + 2]) < 0 ? -1.0 : 1.0;
-            for (int a = 0; a < 3; a++) sum[a] += sgn * nn[3 * j + a];
-        }
-        const double l = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
-        if (l > 0) for (int a = 0; a < 3; a++) ax[a] = sum[a] / l;
-    }
-    auto spread = [&](const double* a, size_t* far) {   // max(theta + beta) about the unit axis a
-        double worst = 0.0;
-        for (size_t j = 0; j < n; j++) {
-            const double c = std::fmin(1.0, std::fabs(a[0] * nn[3 * j] + a[1] * nn[3 * j + 1] + a[2] * nn[3 * j + 2]));
-            const double t = std::acos(c) + beta[j];
-            if (t > worst) { worst = t; if (far) *far = j; }
-        }
-        return worst;
-    };
-    double best_ax[3] = {ax[0], ax[1], ax[2]};
-    size_t far = 0;
-    double best_spread = spread(ax, &far);
-    for (int it = 0; it < 24 && n > 1; it++) {
-        const double step = 0.5 / (it + 2.0);
-        const double sgn = (ax[0] * nn[3 * far] + ax[1] * nn[3 * far + 1] + ax[2] * nn[3 * far + 2]) < 0 ? -1.0 : 1.0;
-        double cand[3];
-        for (int a = 0; a < 3; a++) cand[a] = ax[a] + step * (sgn * nn[3 * far + a] - ax[a]);
-        const double l = std::sqrt(cand[0] * cand[0] + cand[1] * cand[1] + cand[2] * cand[2]);
-        if (!(l > 0)) break;
-        for (int a = 0; a < 3; a++) ax[a] = cand[a] / l;
-        size_t f2 = far;
-        const double sp = spread(ax, &f2);
-        far = f2;
-        if (sp < best_spread) { best_spread = sp; for (int a = 0; a < 3; a++) best_ax[a] = ax[a]; }
-    }
-    int A[3]; double Ad[3], la = 0.0, l1 = 0.0;
-    for (int a = 0; a < 3; a++) { A[a] = (int)std::lround(best_ax[a] * kGuardAxisScale); Ad[a] = A[a]; la += Ad[a] * Ad[a]; l1 += std::fabs(Ad[a]); }
-    la = std::sqrt(la);
-    if (!(la > 0.0)) return always;
-    const double unit[3] = {Ad[0] / la, Ad[1] / la, Ad[2] / la};
-    const double sp = spread(unit, nullptr);
-    if (!(sp < 1.5607)) return always;   // (within half a degree of a right angle)
-    // |A . D - 127 A . d^| <= 0.5 (|Ax| + |Ay| + |Az|) + the rounding of the walk's own normalisation of d (below 0.01 |A|)
-    const double code = std::ceil(std::sin(sp) * la + (0.5 * l1 + 0.01 * la) / 127.0 + 0.02);
-    if (!(code < (double)kGuardAlways)) return always;
-    return ((uint32_t)(A[0] & 0xFF)) | ((uint32_t)(A[1] & 0xFF) << 8) | ((uint32_t)(A[2] & 0xFF) << 16) | ((uint32_t)code << 24);
 }
 
 // A node of the combined binary forest: the meshes' own nodes plus the virtual nodes above their roots.
@@ -335,27 +260,31 @@ inline WideTree build_wide_tree(const OrionMeshDesc* meshes, uint32_t n_meshes, 
             }
         }
         wn.ref0 = refs[0]; wn.ref1 = refs[1]; wn.ref2 = refs[2]; wn.ref3 = refs[3];
-        for (size_t k = 0; k < 4; k++) {
-            if (refs[k] == kWideEmpty) continue;
-            std::vector<uint32_t> below;
-            std::vector<uint32_t> todo(1, slots[k]);
-            while (!todo.empty()) {
-                const BNode& c = bn[todo.back()]; todo.pop_back();
-                if (c.leaf) { for (uint32_t t = 0; t < c.count; t++) below.push_back(c.first + t); }
-                else { todo.push_back(c.child[0]); todo.push_back(c.child[1]); }
-            }
-            wn.guard[k] = guard_word(tris, below);
-        }
         out.nodes[job.index] = wn;
         need[job.index] = (uint32_t)slots.size() - 1;
     }
     out.src_mesh.resize(out.nodes.size(), 0xFFFFFFFFu); out.src_node.resize(out.nodes.size(), 0xFFFFFFFFu);
-    {   // the largest |e1| |e2|: rays no longer than kGuardHarmless over it cannot be accepted by an ill-conditioned test
+    {   // The guard's per-triangle data (wide_walk.h, wide_guard.h).  A triangle's test is ill conditioned for a direction d
+        // when |d . (e1 x e2)| < kGuardKappa |d| |e1| |e2|, that is |d^ . n^| < kGuardKappa / sin(apex): a band of half-width
+        // beta = asin(kGuardKappa / sin(apex)) around the great circle perpendicular to the unit normal n^ (apex: the angle
+        // between the edge vectors).  A triangle without a normal (or a needle: sin(apex) <= kGuardKappa) is ill
+        // conditioned for every direction.  And the largest |e1| |e2| of the scene: rays no longer than kGuardHarmless
+        // over it cannot be accepted by an ill-conditioned test at all.
         double m_max = 0.0;
-        for (const Tri& T : tris) {
-            const double a = (double)T.e1[0] * T.e1[0] + (double)T.e1[1] * T.e1[1] + (double)T.e1[2] * T.e1[2];
-            const double b = (double)T.e2[0] * T.e2[0] + (double)T.e2[1] * T.e2[1] + (double)T.e2[2] * T.e2[2];
-            m_max = std::fmax(m_max, std::sqrt(a * b));
+        out.bands.resize(tris.size());
+        for (size_t i = 0; i < tris.size(); i++) {
+            const Tri& T = tris[i];
+            const double e1[3] = {T.e1[0], T.e1[1], T.e1[2]}, e2[3] = {T.e2[0], T.e2[1], T.e2[2]};
+            const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const double m = std::sqrt((e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) * (e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]));
+            const double lc = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+            m_max = std::fmax(m_max, m);
+            GuardBand b = {{0.0f, 0.0f, 0.0f}, 2.0f};
+            if (lc > 0.0 && m > 0.0 && std::isfinite(lc) && std::isfinite(m) && lc / m > 1.001 * (double)kGuardKappa) {
+                for (int a = 0; a < 3; a++) b.n[a] = (float)(c[a] / lc);
+                b.sin_beta = (float)(1.001 * (double)kGuardKappa * m / lc + 1e-7);    // (+ the rounding of the normal's components)
+            }
+            out.bands[i] = b;
         }
         out.guard_dlen = (m_max > 0.0 && std::isfinite(m_max)) ? (float)((double)kGuardHarmless / m_max * 0.999) : 0.0f;
     }

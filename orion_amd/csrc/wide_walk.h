@@ -33,24 +33,26 @@
 //     triangle's plane) nothing bounds t, u, v: they are rounding residue over a tiny determinant, and the reference accepts
 //     them one time in ten -- UNLESS |d||e1||e2| <= kGuardHarmless = 2.0e-3, for then |det| <= (kappa + 6.5 eps) |d||e1||e2| <
 //     1e-6 and the reference itself rejects the triangle (orion/geometry.hpp:103).
-//     Every slot therefore carries a cone around the normals of the triangles below it (WideNode::guard, built by
-//     wide_bvh.h: guard_word): a slot is DANGEROUS for a ray if the cone admits a triangle that is ill conditioned for its
-//     direction.  A dangerous leaf is visited whatever its box says, as in the reference; a dangerous inner slot iff the ray
-//     meets its grown box anywhere (if not, the reference's test of that node's own box fails too); and neither is ever
-//     dropped for beginning beyond the best hit.  Rays no longer than kGuardHarmless / (the scene's largest |e1||e2|) need
-//     no guard.  With that, every triangle the reference accepts is either tested here or provably cannot beat the result.
-//     What it costs: the cone of a handful of bumpy triangles is wide (nanosuit: a leaf of four is dangerous for 42 % of all
-//     directions, a subtree of 64 for 94 %), so on scenes of large triangles a ray that crosses the model visits 3.3 times
-//     the nodes of the unguarded walk, a bounce ray 1.25 times (oracle/wide_model.cpp; a scene of small triangles, none).
-//     Option "wide_guard" = 0 switches the guard off: the walk then differs from the reference on rays aimed ALONG a
-//     triangle's plane at a slope below 1e-5 (349 of 2^30 such rays on a 19 058-triangle model, none of 1.6 * 10^10 natural
-//     rays: tools/ab/stress_wide.py).
+//     The scene therefore carries a table (wide_guard.h; built on the device when the scene is created): for every node and
+//     every cell of a grid over all ray directions, four bits -- may slot k hold a triangle that is ill conditioned for SOME
+//     direction of the cell.  A slot whose bit is set for the ray's cell is DANGEROUS.  A dangerous leaf is visited whatever
+//     its box says, as in the reference; a dangerous inner slot iff the ray meets its grown box anywhere (if not, the
+//     reference's test of that node's own box fails too); and neither is ever dropped for beginning beyond the best hit.
+//     Rays no longer than kGuardHarmless / (the scene's largest |e1||e2|) need no guard.  With that, every triangle the
+//     reference accepts is either tested here or provably cannot beat the result.
+//     What it costs: one more byte loaded per node step, and the subtrees that are opened for nothing -- every closed surface
+//     has a silhouette for every direction, so the top of the tree is dangerous for every ray and the walk opens what the
+//     ray's LINE meets down to where the cells tell the silhouette from the rest (a 19 k-triangle model, wide nodes per ray:
+//     bounce rays 17.6 -> 20.3, rays across the model 21.0 -> 50.4; a scene of small triangles: none).  Option "wide_guard" = 0
+//     switches the guard off: the walk then differs from the reference on rays aimed ALONG a triangle's plane at a slope
+//     below 1e-5 (349 of 2^30 such rays on that model, none of 1.6 * 10^10 natural rays: tools/ab/stress_wide.py).
 //   * Rays the argument does not cover -- an origin component that is not finite or beyond the scene's
 //     bound, a direction component that is zero, denormal, not finite or outside 2^-40 .. 2^40 -- and
 //     lanes whose stack would overflow take the unculled walk (traverse_lane) instead.
 #pragma once
 
 #include "intersect.h"
+#include "wide_guard.h"
 
 namespace orion_dev {
 
@@ -101,33 +103,17 @@ __device__ __forceinline__ float vmax3_abs(float a, float b, float c) { float r;
 // (the lower bounds if it runs up the axis, the upper bounds if it runs down) and where it leaves them.
 struct WideBytes { uint32_t nx, ny, nz, fx, fy, fz; };
 
-// The guard (see the header comment): the ray's direction as two words of signed bytes, D = d^ * 127 rounded, in the
-// forms (Dx, Dy, Dz, -127) and (-Dx, -Dy, -Dz, -127).  A slot's guard word is (Ax, Ay, Az, c) (wide_bvh.h: guard_word), so the two
-// byte-wise dot products are A . D - 127 c and -(A . D) - 127 c: both negative iff |A . D| < 127 c, the slot may then
-// hold a triangle whose test is ill conditioned for this ray.  Both words zero: the guard is off for the ray.
-struct WideGuard { uint32_t dp, dm; };
+// The guard (see the header comment): the cell of the ray's direction in the scene's table of dangerous slots
+// (wide_guard.h), or kGuardNoCell for a ray that needs no guard.
+struct WideGuard { uint32_t cell; };
 
 __device__ __forceinline__ WideGuard wide_guard_of(const SceneView& S, V3 d) {
-    WideGuard g; g.dp = 0u; g.dm = 0u;
+    WideGuard g; g.cell = kGuardNoCell;
     const float l2 = fmaf(d.x, d.x, fmaf(d.y, d.y, d.z * d.z));
     // Rays no longer than wide_guard_dlen (with room for this sum's rounding) cannot be accepted by an ill-conditioned test
     // (device_types.h: kGuardHarmless).  Tame directions (wide_tame) have components between 2^-40 and 2^40: l2 is a normal number.
-    if (S.wide_guard != 0u && !(l2 * 1.00001f <= S.wide_guard_dlen * S.wide_guard_dlen)) {
-        const float r = 127.0f * __frsqrt_rn(l2);
-        const int x = __float2int_rn(d.x * r), y = __float2int_rn(d.y * r), z = __float2int_rn(d.z * r);   // (|.| <= 127 up to the rounding of r: clamped)
-        const int cx = max(-127, min(127, x)), cy = max(-127, min(127, y)), cz = max(-127, min(127, z));
-        g.dp = (uint32_t)(cx & 0xFF) | (uint32_t)(cy & 0xFF) << 8 | (uint32_t)(cz & 0xFF) << 16 | 0x81000000u;
-        g.dm = (uint32_t)(-cx & 0xFF) | (uint32_t)(-cy & 0xFF) << 8 | (uint32_t)(-cz & 0xFF) << 16 | 0x81000000u;
-    }
+    if (S.wide_guard != 0u && !(l2 * 1.00001f <= S.wide_guard_dlen * S.wide_guard_dlen)) g.cell = guard_cell_of(d.x, d.y, d.z, S.wide_cells_grid);
     return g;
-}
-
-__device__ __forceinline__ bool wide_danger(uint32_t word, WideGuard g) {
-    // (the three-operand form with a zero accumulator: the builtin picks the accumulating form and a move to clear it)
-    int a, b;
-    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(a) : "v"(word), "v"(g.dp));
-    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(b) : "v"(word), "v"(g.dm));
-    return max(a, b) < 0;
 }
 
 // Slot K: its entry distance, or +inf if it is not to be visited; `keep` = it may not be dropped later however near the
@@ -159,6 +145,8 @@ __device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 
 __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv, float best, WideState& w, uint32_t tid, WideGuard g, bool guard) {
     const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
     float4 A = np[0], B = np[1], C = np[2], D = np[3];
+    uint8_t cells = 0;
+    if (guard && g.cell != kGuardNoCell) cells = S.wide_cells[(size_t)w.cur * S.wide_cells_row + (g.cell >> 1)];
     pin(A); pin(B); pin(C); pin(D);
     const float inf = __builtin_inff();
     float t0 = inf, t1 = inf, t2 = inf, t3 = inf;
@@ -186,15 +174,12 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
         const uint32_t lx = __float_as_uint(C.x), ly = __float_as_uint(C.y), lz = __float_as_uint(C.z);
         const uint32_t hx = __float_as_uint(C.w), hy = __float_as_uint(D.x), hz = __float_as_uint(D.y);
         const WideBytes q = {ux ? lx : hx, uy ? ly : hy, uz ? lz : hz, ux ? hx : lx, uy ? hy : ly, uz ? hz : lz};
-        // Which slots are dangerous: only in waves that hold a ray that needs the guard (the others skip the node's fifth
-        // load and these instructions; a ray that needs none carries zero words, for which no slot is dangerous).  The slot
-        // test itself has one form.
+        // Which slots are dangerous: four bits of the node's row of the table (wide_guard.h), asked for together with the
+        // node; only in waves that hold a ray that needs the guard.  The slot test itself has one form.
         bool d0 = false, d1 = false, d2 = false, d3 = false;
         if (guard) {
-            float4 G = np[4];
-            pin(G);
-            d0 = wide_danger(__float_as_uint(G.x), g); d1 = wide_danger(__float_as_uint(G.y), g);
-            d2 = wide_danger(__float_as_uint(G.z), g); d3 = wide_danger(__float_as_uint(G.w), g);
+            const uint32_t bits = g.cell == kGuardNoCell ? 0u : (uint32_t)cells >> ((g.cell & 1u) << 2);   // (two cells per byte)
+            d0 = (bits & 1u) != 0u; d1 = (bits & 2u) != 0u; d2 = (bits & 4u) != 0u; d3 = (bits & 8u) != 0u;
         }
         t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, d0, k0);
         t1 = wide_slot_guarded<1>(q, c, l, u, best, r1, d1, k1);
@@ -292,7 +277,7 @@ __device__ __forceinline__ bool traverse_wide_walk(const SceneView& S, V3 o, V3 
     WideState w; w.cur = 0u; w.sp = 0u; w.best_slot = 0u;
     bool ok = true;
     const WideGuard g = wide_guard_of(S, d);
-    const bool guard = __any(g.dp != 0u);
+    const bool guard = __any(g.cell != kGuardNoCell);
     // The lanes of the wave that walk do so together: node steps until nobody is at a node or kStaticQuorum lanes
     // wait at a leaf (they would idle while the others walk on), then the leaves (nanosuit frame with four
     // bounces: +13 % against "every lane to its next leaf first"; 8, 12 and 16 lanes within 2 % of each other).
