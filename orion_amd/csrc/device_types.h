@@ -164,12 +164,12 @@ struct SceneView {
     float wide_org_bound;    // rays with an origin component beyond this take the unculled walk
     // The guard of the walk's unproven skips (wide_walk.h): on unless the caller switched it off (0), and only
     // for rays longer than wide_guard_dlen = kGuardHarmless / (the largest |e1| |e2| of the scene's triangles).
-    // wide_cells: per wide node a row of wide_cells_row bytes, four bits per cell of the wide_cells_grid^2 grid over
-    // the ray directions (wide_guard.h): bit k = slot k may hold a triangle that is ill conditioned for a direction of the cell.
+    // wide_cells: four bits per wide node and cell of the wide_cells_grid^2 grid over the ray directions (wide_guard.h:
+    // guard_table_offset): bit k = slot k may hold a triangle that is ill conditioned for a direction of the cell.
     uint32_t wide_guard;
     float wide_guard_dlen;
     const uint8_t* wide_cells;
-    uint32_t wide_cells_grid, wide_cells_row;
+    uint32_t wide_cells_grid;
 };
 
 // Closest-hit record kept in the queues: 16 bytes.  gtri == kInvalid is a miss.

@@ -689,15 +689,16 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
         {
             uint32_t G = guard_grid_for(wide.nodes.size());
             if (const char* e = std::getenv("ORION_HIP_GUARD_GRID")) { const int g = std::atoi(e); if (g == 32 || g == 64 || g == 128 || g == 256) G = (uint32_t)g; }   // (A/B runs)
-            const uint32_t row = G * G / 2u;
+            const size_t bytes = guard_table_bytes(wide.nodes.size(), G);
             const GuardBand* d_bands = nullptr;
             if ((rc = upload(s, wide.bands, &d_bands))) return bail(rc);
             void* table = nullptr;
-            if (hipMalloc(&table, (size_t)wide.nodes.size() * row) != hipSuccess) { (void)hipGetLastError(); return bail(fail(2, "scene_create: out of device memory for the wide walk's guard table")); }
+            if (hipMalloc(&table, bytes) != hipSuccess) { (void)hipGetLastError(); return bail(fail(2, "scene_create: out of device memory for the wide walk's guard table")); }
             s->owned.push_back(table);
-            hipLaunchKernelGGL(k_guard_cells, dim3((row + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, v.wide, v.n_wide, d_bands, G, static_cast<uint8_t*>(table), row);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) return bail(fail(2, "scene_create: building the wide walk's guard table failed"));
-            v.wide_cells = static_cast<const uint8_t*>(table); v.wide_cells_grid = G; v.wide_cells_row = row;
+            bool ok = hipMemsetAsync(table, 0, bytes, s->stream) == hipSuccess;
+            if (ok) hipLaunchKernelGGL(k_guard_cells, dim3((G * G + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, v.wide, v.n_wide, d_bands, G, static_cast<uint8_t*>(table));
+            if (!ok || hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) return bail(fail(2, "scene_create: building the wide walk's guard table failed"));
+            v.wide_cells = static_cast<const uint8_t*>(table); v.wide_cells_grid = G;
         }
         v.wide_guard = 1u; v.wide_guard_dlen = wide.guard_dlen;
     }

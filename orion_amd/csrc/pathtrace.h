@@ -490,40 +490,35 @@ __global__ __launch_bounds__(kBlock) ORION_DRAW_ATTR void k_query_wide(SceneView
 }
 
 // --- the wide walk's guard table -------------------------------------------------
-// Four bits per node and direction cell (wide_guard.h), two cells to a byte: one thread per byte of a node's row walks the
-// node array from the back -- a node's children stand behind it, so an inner slot's bit is "the child's four bits are not all
-// zero", read from the row this thread wrote earlier -- and tests a leaf slot's triangles against its two cells.  The node
-// and band records are the same for all threads at any moment (scalar loads), the table's bytes coalesce.
+// Four bits per node and direction cell (wide_guard.h).  One thread per cell walks the node array from the back -- a
+// node's children stand behind it, so an inner slot's bit is "the child's four bits are not all zero", read from what this
+// thread wrote earlier -- and tests a leaf slot's triangles against its cell.  The node and band records are the same for
+// all threads at any moment (scalar loads).  The table must be zero when the kernel starts.
 __global__ __launch_bounds__(kBlock) void k_guard_cells(const WideNode* __restrict__ nodes, uint32_t n_nodes, const GuardBand* __restrict__ bands,
-                                                        uint32_t G, uint8_t* table, uint32_t row) {
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= row) return;
-    float ca[3], cb[3], sa, ka, sb, kb;
-    guard_cell_geometry(G, 2u * t, ca, sa, ka);
-    guard_cell_geometry(G, 2u * t + 1u, cb, sb, kb);
+                                                        uint32_t G, uint8_t* table) {
+    const uint32_t cell = blockIdx.x * kBlock + threadIdx.x, n_cells = G * G;
+    if (cell >= n_cells) return;
+    float c[3], sr, cr;
+    guard_cell_geometry(G, cell, c, sr, cr);
     for (uint32_t i = n_nodes; i-- > 0u;) {
         const WideNode n = nodes[i];
         const uint32_t refs[4] = {n.ref0, n.ref1, n.ref2, n.ref3};
-        uint32_t byte = 0u;
+        uint32_t bits = 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 4u; k++) {
             const uint32_t ref = refs[k];
             if (ref == kWideEmpty) continue;
-            bool a = false, b = false;
+            bool a = false;
             if (ref & kWideLeaf) {
                 const uint32_t first = ref & 0x01FFFFFFu, count = (ref >> 25) & 63u;
-                for (uint32_t s2 = 0; s2 < count; s2++) {
-                    const GuardBand band = bands[first + s2];
-                    a = a || guard_band_meets_cell(band, ca, sa, ka);
-                    b = b || guard_band_meets_cell(band, cb, sb, kb);
-                }
+                for (uint32_t s2 = 0; s2 < count; s2++) a = a || guard_band_meets_cell(bands[first + s2], c, sr, cr);
             } else {
-                const uint32_t child = table[(size_t)ref * row + t];
-                a = (child & 0x0Fu) != 0u; b = (child & 0xF0u) != 0u;
+                a = (((uint32_t)table[guard_table_offset(ref, cell, n_cells)] >> ((ref & 1u) << 2)) & 15u) != 0u;
             }
-            byte |= (a ? 1u : 0u) << k | (b ? 1u : 0u) << (4u + k);
+            bits |= (a ? 1u : 0u) << k;
         }
-        table[(size_t)i * row + t] = (uint8_t)byte;
+        uint8_t* at = table + guard_table_offset(i, cell, n_cells);    // (the byte's other half belongs to node i ^ 1: this thread's too)
+        *at = (uint8_t)(*at | (bits << ((i & 1u) << 2)));
     }
 }
 

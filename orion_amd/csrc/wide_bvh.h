@@ -294,6 +294,33 @@ inline WideTree build_wide_tree(const OrionMeshDesc* meshes, uint32_t n_meshes, 
         total[i] = need[i] + (parent[i] == 0xFFFFFFFFu ? 0 : total[parent[i]]);
         out.stack_need = std::max(out.stack_need, total[i]);
     }
+    // Renumber the nodes depth first (a node, then its slots' subtrees in slot order): a subtree is then a contiguous range
+    // of the array, children still stand behind their parents, and the nodes a ray visits at the bottom of the tree lie close
+    // together -- which is what the guard's table is laid out for (wide_guard.h: guard_table_offset).
+    {
+        const size_t n = out.nodes.size();
+        std::vector<uint32_t> new_of(n, 0xFFFFFFFFu), order;
+        order.reserve(n);
+        std::vector<uint32_t> todo(1, 0u);
+        while (!todo.empty()) {
+            const uint32_t i = todo.back(); todo.pop_back();
+            new_of[i] = (uint32_t)order.size();
+            order.push_back(i);
+            const WideNode& w = out.nodes[i];
+            const uint32_t refs[4] = {w.ref3, w.ref2, w.ref1, w.ref0};     // (pushed in reverse: slot 0's subtree comes first)
+            for (uint32_t r : refs) if (r != kWideEmpty && !(r & kWideLeaf)) todo.push_back(r);
+        }
+        if (order.size() != n) return refuse("the wide tree does not reach all of its nodes");
+        std::vector<WideNode> nodes(n);
+        std::vector<uint32_t> src_mesh(n), src_node(n);
+        for (size_t k = 0; k < n; k++) {
+            WideNode w = out.nodes[order[k]];
+            uint32_t* refs[4] = {&w.ref0, &w.ref1, &w.ref2, &w.ref3};
+            for (uint32_t* r : refs) if (*r != kWideEmpty && !(*r & kWideLeaf)) *r = new_of[*r];
+            nodes[k] = w; src_mesh[k] = out.src_mesh[order[k]]; src_node[k] = out.src_node[order[k]];
+        }
+        out.nodes.swap(nodes); out.src_mesh.swap(src_mesh); out.src_node.swap(src_node);
+    }
     return out;
 }
 

@@ -84,13 +84,25 @@ ORION_GUARD_FN bool guard_band_meets_cell(const GuardBand& b, const float centre
     return fabsf(centre[0] * b.n[0] + centre[1] * b.n[1] + centre[2] * b.n[2]) < lim;
 }
 
-// Grid size for a tree of n_nodes wide nodes: rows of G * G / 2 bytes per node.  A finer grid opens fewer subtrees, but
-// the walk reads one byte of the table per node step, scattered, and a table that outgrows the caches costs more in
-// waiting than its precision saves: on a 19 k-triangle model (5 018 nodes) G = 32 / 64 / 128 / 256 (2.5 / 10 / 41 / 164 MB)
-// gave 3.46 / 3.29 / 3.16 / 3.09 G bounce rays/s and 1.22 / 1.26 / 1.31 / 1.36 G rays/s across the model.  So: the finest
-// grid whose table stays within 32 MiB, and no coarser than 32 x 32 (cells about 3 degrees in radius).
+// Where the four bits of (node, cell) live: the table is cut into blocks of 128 consecutive nodes, and a block holds one
+// 64-byte line per cell with its 128 nodes' bits side by side.  Nodes are numbered depth first (wide_bvh.h), so the nodes a
+// ray visits at the bottom of the tree fall into one or two blocks and the ray -- which asks about one cell only -- finds
+// their bits in the line it already has, instead of one line per node step.  Returns the byte; the node's bits are its
+// low half if the node's index is even, else its high half.
+constexpr uint32_t kGuardBlockLog2 = 7;     // 128 nodes: 64 bytes of bits per cell
+ORION_GUARD_FN size_t guard_table_offset(uint32_t node, uint32_t cell, uint32_t n_cells) {
+    return (((size_t)(node >> kGuardBlockLog2) * n_cells + cell) << 6) + ((node & 127u) >> 1);
+}
+inline size_t guard_table_bytes(uint64_t n_nodes, uint32_t G) { return (size_t)((n_nodes + 127u) >> kGuardBlockLog2) * G * G * 64u; }
+
+// Grid size for a tree of n_nodes wide nodes: G * G / 2 bytes per node.  A finer grid opens fewer subtrees, but the walk
+// reads a byte of the table per node step, and with some 400 000 rays in flight, each asking about its own cell, a table
+// beyond the L2's few megabytes answers from farther away: what the precision saves in visits the node steps lose in
+// waiting.  On a 19 k-triangle model (5 018 nodes) G = 32 / 64 / 128 / 256 (2.6 / 10 / 41 / 164 MB) gave 3.51 / 3.30 / 3.22 /
+// 3.19 G bounce rays/s and 1.25 / 1.31 / 1.37 / 1.40 G rays/s across the model.  So: the finest grid whose table stays within
+// 8 MiB, and no coarser than 32 x 32 (cells about 3 degrees in radius).
 inline uint32_t guard_grid_for(uint64_t n_nodes) {
-    const uint64_t budget = 32ull << 20;
+    const uint64_t budget = 8ull << 20;
     for (uint32_t g = 256u; g > 32u; g >>= 1)
         if (n_nodes * (uint64_t)(g * g / 2u) <= budget) return g;
     return 32u;

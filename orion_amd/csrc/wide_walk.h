@@ -43,7 +43,7 @@
 //     What it costs: one more byte loaded per node step, and the subtrees that are opened for nothing -- every closed surface
 //     has a silhouette for every direction, so the top of the tree is dangerous for every ray and the walk opens what the
 //     ray's LINE meets down to where the cells tell the silhouette from the rest (a 19 k-triangle model, wide nodes per ray:
-//     bounce rays 17.6 -> 20.3, rays across the model 21.0 -> 50.4; a scene of small triangles: none).  Option "wide_guard" = 0
+//     bounce rays 17.6 -> 20.9, rays across the model 21.0 -> 56.8; a scene of small triangles: none).  Option "wide_guard" = 0
 //     switches the guard off: the walk then differs from the reference on rays aimed ALONG a triangle's plane at a slope
 //     below 1e-5 (349 of 2^30 such rays on that model, none of 1.6 * 10^10 natural rays: tools/ab/stress_wide.py).
 //   * Rays the argument does not cover -- an origin component that is not finite or beyond the scene's
@@ -146,7 +146,7 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
     const float4* np = reinterpret_cast<const float4*>(S.wide + w.cur);
     float4 A = np[0], B = np[1], C = np[2], D = np[3];
     uint8_t cells = 0;
-    if (guard && g.cell != kGuardNoCell) cells = S.wide_cells[(size_t)w.cur * S.wide_cells_row + (g.cell >> 1)];
+    if (guard && g.cell != kGuardNoCell) cells = S.wide_cells[guard_table_offset(w.cur, g.cell, S.wide_cells_grid * S.wide_cells_grid)];
     pin(A); pin(B); pin(C); pin(D);
     const float inf = __builtin_inff();
     float t0 = inf, t1 = inf, t2 = inf, t3 = inf;
@@ -178,7 +178,7 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
         // node; only in waves that hold a ray that needs the guard.  The slot test itself has one form.
         bool d0 = false, d1 = false, d2 = false, d3 = false;
         if (guard) {
-            const uint32_t bits = g.cell == kGuardNoCell ? 0u : (uint32_t)cells >> ((g.cell & 1u) << 2);   // (two cells per byte)
+            const uint32_t bits = g.cell == kGuardNoCell ? 0u : (uint32_t)cells >> ((w.cur & 1u) << 2);   // (two nodes per byte)
             d0 = (bits & 1u) != 0u; d1 = (bits & 2u) != 0u; d2 = (bits & 4u) != 0u; d3 = (bits & 8u) != 0u;
         }
         t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, d0, k0);
