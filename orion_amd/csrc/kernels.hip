@@ -122,6 +122,7 @@ struct OrionScene {
     uint64_t batch_paths = 256u << 20;    // paths in flight per batch (128 B of queues each; less where the device's free memory asks for it)
     uint32_t queue_parts_log2 = kPartsLog2;   // partitions of a render batch's queues (2^n; FrameParams::part_log2)
     uint32_t overlap_below = 128u << 20;   // start the next batch on the other lane once this few rays are left (0: never)
+    uint32_t fail_queue_allocs = 0;       // test hook (ORION_HIP_TEST_HOOKS=1 only): the next n attempts to take a lane's queues fail
     uint32_t fail_at_bounce = 0;          // test hook (ORION_HIP_TEST_HOOKS=1 only): the n-th bounce of the next render call fails
     uint64_t queue_budget = 0;            // bytes the render queues may take (0: three quarters of the device's free memory)
     bool draw_rays = true;                // large scenes: bounce rays are handed to lanes as they finish (k_extend_wide)
@@ -799,6 +800,13 @@ int orion_hip_scene_set_option(OrionScene* s, const char* name, int64_t value) {
     }
     // Test hook, not part of the documented options: only a process started with ORION_HIP_TEST_HOOKS=1 can arm it, for the
     // next render call only.  The n-th bounce that call launches fails with code 3, whatever is in flight.
+    if (!std::strcmp(name, "fail_queue_allocs")) {   // (the other test hook: the next n attempts to take a lane's queues fail as if out of memory)
+        const char* hooks = std::getenv("ORION_HIP_TEST_HOOKS");
+        if (!hooks || std::strcmp(hooks, "1") != 0) return fail(1, "set_option: unknown option 'fail_queue_allocs'");
+        if (value < 0 || value > 64) return fail(1, "set_option: fail_queue_allocs out of range");
+        s->fail_queue_allocs = (uint32_t)value;
+        return 0;
+    }
     if (!std::strcmp(name, "fail_at_bounce")) {
         const char* hooks = std::getenv("ORION_HIP_TEST_HOOKS");
         if (!hooks || std::strcmp(hooks, "1") != 0) return fail(1, "set_option: unknown option 'fail_at_bounce'");
@@ -938,8 +946,35 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
             while (per_batch > 1 && need(per_batch) > budget) per_batch = (per_batch + 1) / 2;
         }
     }
+    if (P * per_batch + kParts * kTileWide >= 0xFFFFFFFFull) return fail(1, "render: tile has too many pixels for one batch");
+    // The queues are taken now, before anything is launched, and the estimate above is only as good as the moment it was
+    // made (another process, another scene, the caller's own tensors may have taken memory since): an allocation that
+    // fails halves the samples per batch and tries again with what is left, down to one sample per batch.
+    const bool wide_queues = s->mode() == MODE_WIDE && s->draw_rays;
+    auto reserve_lane = [&](Lane& L, uint64_t paths) -> int {
+        if (s->fail_queue_allocs) { s->fail_queue_allocs--; return fail(2, "hipMalloc: injected failure (option fail_queue_allocs)"); }
+        const size_t queue_bytes = (size_t)(paths + kParts * kTileWide) * 16;   // (partitions end on tile boundaries)
+        for (DevBuf& b : L.q) if (int rc = b.reserve(queue_bytes)) return rc;
+        if (int rc = L.hits.reserve(queue_bytes)) return rc;
+        if (int rc = L.rad.reserve(paths * 16)) return rc;
+        if (int rc = L.counter.reserve(kRing * kSlotWords * 8)) return rc;
+        if (wide_queues) {
+            if (int rc = L.pre_hits.reserve(paths * 16)) return rc;
+            if (int rc = L.pre_work.reserve(kWorkWords * 4)) return rc;
+        }
+        return 0;
+    };
+    for (;;) {
+        const bool two = (uint64_t)(p->spp_end - p->spp_begin) > per_batch && s->overlap_below != 0;
+        int rc = reserve_lane(s->lane[0], P * per_batch);
+        if (rc == 0 && two) rc = reserve_lane(s->lane[1], P * per_batch);
+        if (rc == 0) break;
+        if (per_batch == 1) { s->fail_queue_allocs = 0; return rc; }
+        (void)hipGetLastError();
+        for (Lane& L : s->lane) { for (DevBuf& b : L.q) b.release(); L.hits.release(); L.rad.release(); L.pre_hits.release(); }
+        per_batch = (per_batch + 1) / 2;
+    }
     const uint64_t max_paths = P * per_batch;
-    if (max_paths + kParts * kTileWide >= 0xFFFFFFFFull) return fail(1, "render: tile has too many pixels for one batch");
 
     const size_t img_bytes = (size_t)p->width * p->height * 16;
     const bool accum_dev = is_device_ptr(accum_any);
@@ -983,16 +1018,8 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
     };
     auto begin = [&](Batch& B, uint64_t index) -> int {
         Lane& L = s->lane[two_lanes ? (index & 1) : 0];
-        const size_t queue_bytes = (size_t)(max_paths + kParts * kTileWide) * 16;   // (partitions end on tile boundaries)
-        for (DevBuf& b : L.q) if (int rc = b.reserve(queue_bytes)) return rc;
-        if (int rc = L.hits.reserve(queue_bytes)) return rc;
-        if (int rc = L.rad.reserve(max_paths * 16)) return rc;
-        if (int rc = L.counter.reserve(kRing * kSlotWords * 8)) return rc;
-        if (draw_rays) {
-            if (int rc = L.pre_hits.reserve(max_paths * 16)) return rc;
-            if (int rc = L.pre_work.reserve(kWorkWords * 4)) return rc;
-            HIP_TRY(hipMemsetAsync(L.pre_work.p, 0, kWorkWords * 4, L.stream));
-        }
+        if (int rc = reserve_lane(L, max_paths)) return rc;      // (taken above: nothing to do)
+        if (draw_rays) HIP_TRY(hipMemsetAsync(L.pre_work.p, 0, kWorkWords * 4, L.stream));
         B = Batch{};
         B.L = &L;
         B.F = F;
@@ -1152,7 +1179,7 @@ int orion_hip_render(OrionScene* s, const OrionCamera* cam, const OrionRenderPar
         return 0;
     };
     const int rc = run();
-    s->fail_at_bounce = 0;   // (the test hook never outlives the call it was armed for)
+    s->fail_at_bounce = 0; s->fail_queue_allocs = 0;   // (the test hooks never outlive the call they were armed for)
     if (rc != 0) {
         const std::string why = g_error;
         for (Lane& L : s->lane) (void)hipStreamSynchronize(L.stream);

@@ -716,6 +716,28 @@ def test_a_failed_render_leaves_the_handle_usable(gpu, monkeypatch):
     sc.close()
 
 
+def test_a_render_call_survives_queue_allocations_that_fail(gpu, monkeypatch):
+    """The queues of a render call are sized from the memory the device has free when the call starts; if taking them fails all
+    the same (somebody else allocated in between), the call halves its samples per batch and tries again.  The test hook
+    makes the first attempts fail; the image must keep its bits (it does not depend on how a call is cut into batches)."""
+    sc = gpu.Scene(conftest.load_model("cornell"), device=0)
+    eye, look, up, yv = CORNELL_CAM
+    W, H, spp = 256, 144, 16
+    cam = gpu.camera_vectors(eye, look, up, yv, W / H)
+    ref = sc.render(cam, W, H, 0, spp, 2, 30, seed=22).copy()
+    monkeypatch.setenv("ORION_HIP_TEST_HOOKS", "1")
+    for n in (1, 2, 3):
+        sc.set_option("fail_queue_allocs", n)
+        img = sc.render(cam, W, H, 0, spp, 2, 30, seed=22)
+        assert np.array_equal(bits(ref), bits(img)), n
+    sc.set_option("fail_queue_allocs", 64)          # more failures than halvings: the call reports the failure ...
+    with pytest.raises(gpu.OrionError, match="hipMalloc"):
+        sc.render(cam, W, H, 0, spp, 2, 30, seed=22)
+    img = sc.render(cam, W, H, 0, spp, 2, 30, seed=22)   # ... and the handle stays usable
+    assert np.array_equal(bits(ref), bits(img))
+    sc.close()
+
+
 def test_batching_and_repetition_change_nothing(gpu):
     """How a render call is cut into batches (option batch_paths), and running it twice, must not
     move a bit: samples are independent and are summed per pixel in ascending sample order."""
