@@ -212,9 +212,9 @@ class WideModel:
         self.h = L.wide_model_create(C.byref(descs), len(model.meshes), why)
         self.why_not = why.value.decode()
         if self.h:
-            info = np.zeros(2, np.uint32); finfo = np.zeros(2, np.float32)
+            info = np.zeros(3, np.uint32); finfo = np.zeros(2, np.float32)
             L.wide_model_info(self.h, _p(info), _p(finfo))
-            self.n_nodes, self.stack_need = int(info[0]), int(info[1])
+            self.n_nodes, self.stack_need, self.n_virtual = int(info[0]), int(info[1]), int(info[2])
             self.pad, self.org_bound = float(finfo[0]), float(finfo[1])
 
     def __del__(self):

@@ -144,7 +144,8 @@ bool walk(Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& st) {
             st.nodes++; my_steps++;
             float a0, b0;
             slab(n.lo, n.hi, o, inv, a0, b0);
-            const bool in = (b0 > a0) && (b0 > 0.0f);
+            // (a virtual node -- no box of the reference's -- is entered whenever one of its slots is dangerous)
+            const bool in = ((b0 > a0) && (b0 > 0.0f)) || (cull == 2 && grow && cur < M.tree.n_virtual && grow[cur] != 0);
             if (!in) st.own_fail++;
             Entry hit[4]; int nh = 0;
             if (in) {
@@ -183,7 +184,7 @@ bool walk(Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& st) {
                         }
                     }
                     // a dangerous inner slot the ray's line misses fails the reference's own box test; a dangerous leaf is visited anyway
-                    if (danger && !(refs[k] & 0x80000000u) && !met) danger = false;
+                    if (danger && !(refs[k] & 0x80000000u) && !(refs[k] < M.tree.n_virtual) && !met) danger = false;
                     const float cull_t = danger ? -1.0f : a;
                     if (danger && !within) st.danger_slots++;
                     if (cull && !within && !danger) continue;
@@ -298,10 +299,10 @@ void* wide_model_create(const OrionMeshDesc* meshes, uint32_t n_meshes, char* wh
 
 void wide_model_destroy(void* h) { delete static_cast<Model*>(h); }
 
-// info[0] = wide nodes, [1] = stack_need; finfo[0] = pad, [1] = org_bound
+// info[0] = wide nodes, [1] = stack_need, [2] = virtual nodes (they come first); finfo[0] = pad, [1] = org_bound
 void wide_model_info(void* h, uint32_t* info, float* finfo) {
     const Model* M = static_cast<Model*>(h);
-    info[0] = (uint32_t)M->tree.nodes.size(); info[1] = M->tree.stack_need;
+    info[0] = (uint32_t)M->tree.nodes.size(); info[1] = M->tree.stack_need; info[2] = M->tree.n_virtual;
     finfo[0] = M->tree.pad; finfo[1] = M->tree.org_bound;
 }
 

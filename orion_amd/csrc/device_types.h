@@ -159,6 +159,7 @@ struct SceneView {
     const WideNode* wide;
     const uint32_t* wide_bin;   // per wide node: index in `nodes` of the binary inner node it stands for (kInvalid: a virtual node)
     uint32_t n_wide;
+    uint32_t wide_n_virtual;    // wide[0 .. wide_n_virtual): the virtual nodes above the meshes' roots
     float wide_pad;          // every decoded slot box, grown by this, contains its real box (wide_bvh.h)
     float wide_grow0;        // wide_pad * (1 + 2 * kWideSlack): what a slot box is grown by before the distance term
     float wide_org_bound;    // rays with an origin component beyond this take the unculled walk

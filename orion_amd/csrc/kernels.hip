@@ -684,7 +684,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
             if (wide.src_mesh[i] != kInvalid) wide_bin[i] = node_where[wide.src_mesh[i]][wide.src_node[i]];
         if ((rc = upload(s, wide_bin, &v.wide_bin))) return bail(rc);
         if ((rc = upload(s, wide.nodes, &v.wide))) return bail(rc);
-        v.n_wide = (uint32_t)wide.nodes.size(); v.wide_pad = wide.pad; v.wide_grow0 = wide.pad * (1.0f + 2.0f * kWideSlack); v.wide_org_bound = wide.org_bound;
+        v.n_wide = (uint32_t)wide.nodes.size(); v.wide_n_virtual = wide.n_virtual; v.wide_pad = wide.pad; v.wide_grow0 = wide.pad * (1.0f + 2.0f * kWideSlack); v.wide_org_bound = wide.org_bound;
         // The guard's table (wide_guard.h): which slots may hold an ill-conditioned triangle, per node and cell of a grid over the
         // ray directions; built on the device, bottom-up (children stand behind their parents in the node array).
         {

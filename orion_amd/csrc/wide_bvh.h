@@ -46,6 +46,7 @@ struct WideTree {
     float pad = 0.0f;              // every decoded slot box, grown by this, contains the real box grown by three quarters of it
     float org_bound = 0.0f;        // rays with an origin component beyond this take the unculled walk
     uint32_t stack_need = 0;       // deepest the ordered walk's stack can get
+    uint32_t n_virtual = 0;        // nodes[0 .. n_virtual) are the virtual nodes above the meshes' roots (no box of theirs exists in the reference)
     float guard_dlen = 0.0f;       // rays whose direction is at most this long need no guard (no triangle is large enough)
     std::vector<GuardBand> bands;  // per triangle slot: unit normal and the half-width of its band of ill-conditioned directions (wide_guard.h)
     std::string why_not;           // set when nodes is empty
@@ -294,21 +295,27 @@ inline WideTree build_wide_tree(const OrionMeshDesc* meshes, uint32_t n_meshes, 
         total[i] = need[i] + (parent[i] == 0xFFFFFFFFu ? 0 : total[parent[i]]);
         out.stack_need = std::max(out.stack_need, total[i]);
     }
-    // Renumber the nodes depth first (a node, then its slots' subtrees in slot order): a subtree is then a contiguous range
-    // of the array, children still stand behind their parents, and the nodes a ray visits at the bottom of the tree lie close
-    // together -- which is what the guard's table is laid out for (wide_guard.h: guard_table_offset).
+    // Renumber the nodes: first the virtual nodes above the meshes' roots, then the others, each group depth first (a node,
+    // then its slots' subtrees in slot order).  A mesh's subtree is then a contiguous range of the array, children still
+    // stand behind their parents, the nodes a ray visits at the bottom of the tree lie close together -- which is what
+    // the guard's table is laid out for (wide_guard.h: guard_table_offset) -- and "is this node virtual" is one comparison
+    // of its index (the walk enters such a node, whose box the reference does not have, whenever one of its slots is
+    // dangerous: a mesh whose tree is one leaf hangs from it, and the reference tests that mesh's triangles whatever the ray).
     {
         const size_t n = out.nodes.size();
         std::vector<uint32_t> new_of(n, 0xFFFFFFFFu), order;
         order.reserve(n);
-        std::vector<uint32_t> todo(1, 0u);
-        while (!todo.empty()) {
-            const uint32_t i = todo.back(); todo.pop_back();
-            new_of[i] = (uint32_t)order.size();
-            order.push_back(i);
-            const WideNode& w = out.nodes[i];
-            const uint32_t refs[4] = {w.ref3, w.ref2, w.ref1, w.ref0};     // (pushed in reverse: slot 0's subtree comes first)
-            for (uint32_t r : refs) if (r != kWideEmpty && !(r & kWideLeaf)) todo.push_back(r);
+        for (int pass = 0; pass < 2; pass++) {
+            std::vector<uint32_t> todo(1, 0u);
+            while (!todo.empty()) {
+                const uint32_t i = todo.back(); todo.pop_back();
+                const bool virt = out.src_mesh[i] == 0xFFFFFFFFu;
+                if (virt == (pass == 0)) { new_of[i] = (uint32_t)order.size(); order.push_back(i); }
+                const WideNode& w = out.nodes[i];
+                const uint32_t refs[4] = {w.ref3, w.ref2, w.ref1, w.ref0};     // (pushed in reverse: slot 0's subtree comes first)
+                for (uint32_t r : refs) if (r != kWideEmpty && !(r & kWideLeaf)) todo.push_back(r);
+            }
+            if (pass == 0) out.n_virtual = (uint32_t)order.size();
         }
         if (order.size() != n) return refuse("the wide tree does not reach all of its nodes");
         std::vector<WideNode> nodes(n);

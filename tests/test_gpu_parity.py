@@ -137,6 +137,41 @@ def test_leaf_root_mesh_on_the_face_of_a_large_scene(gpu):
     sc.close()
 
 
+def test_rays_along_a_leaf_root_mesh_among_many_meshes(gpu):
+    """Nine meshes: the one whose tree is a single leaf (a quad) hangs below the wide tree's nodes above the meshes' roots,
+    nodes whose boxes the reference does not have.  Rays in the quad's plane: the reference tests the quad's triangles
+    for every one of them and accepts rounding residue on a few (orion/geometry.hpp:96-124); the wide walk must return
+    the same bits, in every traversal."""
+    from orion_amd import host
+    from oracle import bindings as ob
+    v, i = raygen.triangle_soup(4000, edge=0.03, seed=5)
+    q = np.zeros((4, 8), np.float32)
+    q[:, 0] = [0.2, 0.8, 0.8, 0.2]; q[:, 1] = 1.3; q[:, 2] = [0.2, 0.2, 0.8, 0.8]; q[:, 4] = 1.0
+    parts = [host.model_from_arrays(v, i), host.model_from_arrays(q, np.array([0, 1, 2, 0, 2, 3], np.uint32))]
+    for dx, dz in (3.0, 0.0), (0.0, 3.0), (6.0, 0.0), (0.0, 6.0), (6.0, 6.0), (-3.0, 0.0), (0.0, -3.0):
+        vv = v.copy(); vv[:, 0] += dx; vv[:, 2] += dz
+        parts.append(host.model_from_arrays(vv, i))
+    model = host.merge_models(parts)
+    assert model.meshes[1].nodes["is_leaf"][0]
+    rng = np.random.default_rng(1)
+    n = 1 << 19
+    p = np.stack([rng.uniform(-9, 12, n), np.full(n, 1.3), rng.uniform(-9, 12, n)], 1)
+    ang = rng.random(n) * 2 * np.pi
+    slope = 10.0 ** rng.uniform(-7.5, -5, n) * rng.choice([-1, 1], n)
+    d = np.stack([np.cos(ang), slope, np.sin(ang)], 1)
+    o = (p - d * rng.uniform(0.1, 3, n)[:, None]).astype(np.float32)
+    d = (d * (10.0 ** rng.uniform(-1, 1, n))[:, None]).astype(np.float32)
+    oid, otuv = ob.OracleScene(model).closest_hit(o, d, threads=8)
+    assert (oid[:, 0] == 1).sum() > 20          # the quad is "hit" by some of them
+    sc = gpu.Scene(model, device=0)
+    for mode in (0, 1, 4):
+        sc.set_option("traversal", mode)
+        ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+        assert np.array_equal(ids, oid), f"traversal {mode}: ids"
+        assert np.array_equal(bits(tuv), bits(otuv)), f"traversal {mode}: t,u,v bits"
+    sc.close()
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_any_hit_golden(gpu, name):
     g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))

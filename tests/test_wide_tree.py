@@ -79,6 +79,17 @@ def test_wide_tree_structure():
     wm = ob.WideModel(model)
     assert wm.h and wm.n_nodes > 1000 and 0 < wm.stack_need <= 32
     assert wm.pad == pytest.approx(2.0 ** -12 * max(abs(float(x)) for m in model.meshes for x in (m.vertices[:, :3].min(), m.vertices[:, :3].max())), rel=1e-6)
+    # numbering: the virtual nodes above the meshes' roots first, children behind their parents, nothing below a mesh's
+    # own node points back up into the virtual ones
+    words, _ = wm.nodes()
+    refs = words[:, [3, 7, 14, 15]]
+    inner = (refs != 0x7FFFFFFF) & (refs < 0x80000000)
+    assert len(model.meshes) > 4 and 0 < wm.n_virtual < wm.n_nodes
+    assert (refs[inner] < wm.n_nodes).all()
+    assert (refs > np.arange(wm.n_nodes, dtype=np.uint32)[:, None])[inner].all()
+    assert (refs[wm.n_virtual:][inner[wm.n_virtual:]] >= wm.n_virtual).all()
+    reached = np.zeros(wm.n_nodes, bool); reached[0] = True; reached[refs[inner]] = True
+    assert reached.all() and inner.sum() == wm.n_nodes - 1
 
 
 def test_scenes_the_wide_tree_refuses():
