@@ -72,7 +72,7 @@ const uint8_t* cell_row(Model& M, uint32_t cell) {
             if (ref & 0x80000000u) {
                 const uint32_t first = ref & 0x1FFFFFFu, count = (ref >> 25) & 63u;
                 for (uint32_t s = first; s < first + count && !a; s++) a = orion_dev::guard_band_meets_cell(M.tree.bands[s], c, sr, cr);
-            } else a = row[ref] != 0;
+            } else if (i >= M.tree.n_virtual || ref < M.tree.n_virtual) a = row[ref] != 0;   // (virtual nodes: forced slots only -- never a mesh's own inner node)
             if (a) bits |= (uint8_t)(1u << k);
         }
         row[i] = bits;
@@ -145,7 +145,8 @@ bool walk(Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& st) {
             float a0, b0;
             slab(n.lo, n.hi, o, inv, a0, b0);
             // (a virtual node -- no box of the reference's -- is entered whenever one of its slots is dangerous)
-            const bool in = ((b0 > a0) && (b0 > 0.0f)) || (cull == 2 && grow && cur < M.tree.n_virtual && grow[cur] != 0);
+            const bool vrule = cull == 2 && grow && cur < M.tree.n_virtual;   // (the product's rule for virtual nodes: wide_walk.h)
+            const bool in = ((b0 > a0) && (b0 > 0.0f)) || (vrule && grow[cur] != 0);
             if (!in) st.own_fail++;
             Entry hit[4]; int nh = 0;
             if (in) {
@@ -184,7 +185,8 @@ bool walk(Model& M, V3 o, V3 d, int cull, float kappa, Best& best, Stats& st) {
                         }
                     }
                     // a dangerous inner slot the ray's line misses fails the reference's own box test; a dangerous leaf is visited anyway
-                    if (danger && !(refs[k] & 0x80000000u) && !(refs[k] < M.tree.n_virtual) && !met) danger = false;
+                    if (vrule) danger = danger || met;      // bit: forced whatever the box; otherwise visited iff met, never dropped by distance
+                    else if (danger && !(refs[k] & 0x80000000u) && !met) danger = false;
                     const float cull_t = danger ? -1.0f : a;
                     if (danger && !within) st.danger_slots++;
                     if (cull && !within && !danger) continue;

@@ -697,7 +697,7 @@ int orion_hip_scene_create(const OrionMeshDesc* meshes, uint32_t n_meshes,
             if (hipMalloc(&table, bytes) != hipSuccess) { (void)hipGetLastError(); return bail(fail(2, "scene_create: out of device memory for the wide walk's guard table")); }
             s->owned.push_back(table);
             bool ok = hipMemsetAsync(table, 0, bytes, s->stream) == hipSuccess;
-            if (ok) hipLaunchKernelGGL(k_guard_cells, dim3((G * G + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, v.wide, v.n_wide, d_bands, G, static_cast<uint8_t*>(table));
+            if (ok) hipLaunchKernelGGL(k_guard_cells, dim3((G * G + kBlock - 1) / kBlock), dim3(kBlock), 0, s->stream, v.wide, v.n_wide, v.wide_n_virtual, d_bands, G, static_cast<uint8_t*>(table));
             if (!ok || hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) return bail(fail(2, "scene_create: building the wide walk's guard table failed"));
             v.wide_cells = static_cast<const uint8_t*>(table); v.wide_cells_grid = G;
         }

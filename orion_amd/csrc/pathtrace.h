@@ -494,8 +494,11 @@ __global__ __launch_bounds__(kBlock) ORION_DRAW_ATTR void k_query_wide(SceneView
 // node's children stand behind it, so an inner slot's bit is "the child's four bits are not all zero", read from what this
 // thread wrote earlier -- and tests a leaf slot's triangles against its cell.  The node and band records are the same for
 // all threads at any moment (scalar loads).  The table must be zero when the kernel starts.
-__global__ __launch_bounds__(kBlock) void k_guard_cells(const WideNode* __restrict__ nodes, uint32_t n_nodes, const GuardBand* __restrict__ bands,
-                                                        uint32_t G, uint8_t* table) {
+// The first n_virtual nodes are the virtual ones above the meshes' roots, whose bits mean something else (wide_walk.h: "the
+// nodes above the meshes' roots"): slot k must be visited whatever its box says -- a leaf (a mesh whose tree is one leaf)
+// with an ill-conditioned triangle, or a virtual node with such a slot; a mesh's own inner node never.
+__global__ __launch_bounds__(kBlock) void k_guard_cells(const WideNode* __restrict__ nodes, uint32_t n_nodes, uint32_t n_virtual,
+                                                        const GuardBand* __restrict__ bands, uint32_t G, uint8_t* table) {
     const uint32_t cell = blockIdx.x * kBlock + threadIdx.x, n_cells = G * G;
     if (cell >= n_cells) return;
     float c[3], sr, cr;
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_guard_cells(const WideNode* __restri
             if (ref & kWideLeaf) {
                 const uint32_t first = ref & 0x01FFFFFFu, count = (ref >> 25) & 63u;
                 for (uint32_t s2 = 0; s2 < count; s2++) a = a || guard_band_meets_cell(bands[first + s2], c, sr, cr);
-            } else {
+            } else if (i >= n_virtual || ref < n_virtual) {
                 a = (((uint32_t)table[guard_table_offset(ref, cell, n_cells)] >> ((ref & 1u) << 2)) & 15u) != 0u;
             }
             bits |= (a ? 1u : 0u) << k;

@@ -39,9 +39,12 @@
 //     its box says, as in the reference; a dangerous inner slot iff the ray meets its grown box anywhere (if not, the
 //     reference's test of that node's own box fails too); and neither is ever dropped for beginning beyond the best hit.
 //     The nodes above the meshes' roots (wide_bvh.h: virtual nodes, numbered first) have no box in the reference -- a mesh whose
-//     tree is one leaf hangs from them, and the reference tests its triangles for every ray -- so a dangerous slot that is
-//     such a node is visited like a dangerous leaf, and such a node is entered, whatever its own box says, when one of its
-//     slots is dangerous.
+//     tree is one leaf hangs from them, and the reference tests its triangles for every ray.  For a ray that needs the guard
+//     their slots are therefore never dropped by distance (a slot whose grown box the ray meets anywhere is visited: every
+//     mesh the reference walks into has its root's box inside these boxes), and their bits in the table mean FORCED: slot k
+//     is a leaf with an ill-conditioned triangle, or a virtual node with a forced slot -- visited whatever its box says, and
+//     a virtual node with a forced slot is entered whatever its own box says.  (A mesh's own inner node is never forced: the
+//     reference tests its box.)
 //     Rays no longer than kGuardHarmless / (the scene's largest |e1||e2|) need no guard.  With that, every triangle the
 //     reference accepts is either tested here or provably cannot beat the result.
 //     What it costs: one more byte loaded per node step, and the subtrees that are opened for nothing -- every closed surface
@@ -128,8 +131,10 @@ __device__ __forceinline__ WideGuard wide_guard_of(const SceneView& S, V3 d) {
 // reference's own test of the inner node's box fails too); a dangerous leaf is visited whatever its box says, as in the
 // reference.  Slots visited only because they are dangerous come after the others (distance kWideLast).
 constexpr float kWideLast = 3.0e38f;
+// `vrule`: the lane's ray needs the guard and the node is a virtual one (see the header comment): its slots are visited iff
+// the ray meets their grown box anywhere or their bit is set, and never dropped later.
 template <int K>
-__device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 l, V3 u, float best, uint32_t ref, uint32_t n_virtual, bool danger, bool& keep) {
+__device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 l, V3 u, float best, uint32_t ref, bool vrule, bool bit, bool& keep) {
     const float t1x = fmaf(byte_of<K>(q.nx), c.x, l.x), t2x = fmaf(byte_of<K>(q.fx), c.x, u.x);
     const float t1y = fmaf(byte_of<K>(q.ny), c.y, l.y), t2y = fmaf(byte_of<K>(q.fy), c.y, u.y);
     const float t1z = fmaf(byte_of<K>(q.nz), c.z, l.z), t2z = fmaf(byte_of<K>(q.fz), c.z, u.z);
@@ -137,10 +142,10 @@ __device__ __forceinline__ float wide_slot_guarded(const WideBytes& q, V3 c, V3 
     const float tmax = vmin3(t2x, t2y, t2z);
     const bool met = vmax(tmin, 0.0f) <= tmax;            // the ray meets the grown box somewhere
     const bool within = met & (tmin <= best);
-    // (a virtual node counts as a leaf here: no box of the reference stands between the ray and the leaf-root meshes below it)
-    const bool leaf = (ref & kWideLeaf) != 0u || ref < n_virtual;
+    const bool danger = bit | vrule;                       // not to be dropped by distance
+    const bool boxless = vrule ? bit : (ref & kWideLeaf) != 0u;   // visited even if the box is missed (given `danger`)
     keep = danger;
-    const bool vis = (ref != kWideEmpty) & (within | (danger & (met | leaf)));
+    const bool vis = (ref != kWideEmpty) & (within | (danger & (met | boxless)));
     return vis ? (within ? tmin : kWideLast) : __builtin_inff();
 }
 
@@ -166,8 +171,9 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
     // hold a ray that needs the guard.
     uint32_t bits = 0u;
     if (guard) bits = g.cell == kGuardNoCell ? 0u : ((uint32_t)cells >> ((w.cur & 1u) << 2)) & 15u;   // (two nodes per byte)
-    // A virtual node's box is not the reference's: it is entered whenever one of its slots is dangerous.
-    if ((own_max > own_min && own_max > 0.0f) || (w.cur < S.wide_n_virtual && bits != 0u)) {
+    // A virtual node's box is not the reference's: it is entered whenever one of its slots is forced.
+    const bool vrule = w.cur < S.wide_n_virtual && g.cell != kGuardNoCell;
+    if ((own_max > own_min && own_max > 0.0f) || (vrule && bits != 0u)) {
         // The grid's plane at byte q lies at lo + q * (hi - lo) / 254; its slab distance is s0 + q * (s1 - s0) / 254, and
         // that of a plane moved by g against / along the axis s0 -+ g * inv (the rounding of these forms is
         // ten-thousandths of the slack).  g = pad + slack * (reach + 2 pad), reach = the origin's distance to the
@@ -185,10 +191,10 @@ __device__ __forceinline__ bool wide_node_step(const SceneView& S, V3 o, V3 inv,
         const uint32_t hx = __float_as_uint(C.w), hy = __float_as_uint(D.x), hz = __float_as_uint(D.y);
         const WideBytes q = {ux ? lx : hx, uy ? ly : hy, uz ? lz : hz, ux ? hx : lx, uy ? hy : ly, uz ? hz : lz};
         const bool d0 = (bits & 1u) != 0u, d1 = (bits & 2u) != 0u, d2 = (bits & 4u) != 0u, d3 = (bits & 8u) != 0u;
-        t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, S.wide_n_virtual, d0, k0);
-        t1 = wide_slot_guarded<1>(q, c, l, u, best, r1, S.wide_n_virtual, d1, k1);
-        t2 = wide_slot_guarded<2>(q, c, l, u, best, r2, S.wide_n_virtual, d2, k2);
-        t3 = wide_slot_guarded<3>(q, c, l, u, best, r3, S.wide_n_virtual, d3, k3);
+        t0 = wide_slot_guarded<0>(q, c, l, u, best, r0, vrule, d0, k0);
+        t1 = wide_slot_guarded<1>(q, c, l, u, best, r1, vrule, d1, k1);
+        t2 = wide_slot_guarded<2>(q, c, l, u, best, r2, vrule, d2, k2);
+        t3 = wide_slot_guarded<3>(q, c, l, u, best, r3, vrule, d3, k3);
     }
     const float tn = vmin(vmin3(t0, t1, t2), t3);
     if (!(tn < inf)) { wide_pop(w, best, tid); return true; }

@@ -172,6 +172,28 @@ def test_rays_along_a_leaf_root_mesh_among_many_meshes(gpu):
     sc.close()
 
 
+def test_many_meshes_with_leaf_root_quads(gpu):
+    """340 meshes, 40 of them quads whose tree is one leaf: rays across the scene and rays in the quads' planes return
+    the oracle's bits in every traversal (the wide walk's nodes above the meshes' roots: csrc/wide_walk.h)."""
+    import test_wide_tree as tw
+    from oracle import bindings as ob
+    model = tw.many_meshes_model()
+    n = 1 << 17
+    o, d = raygen.box_rays(model, n, seed=9)
+    o2, d2 = tw.quad_plane_rays(model, n, seed=10)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    oid, otuv = ob.OracleScene(model).closest_hit(o, d, threads=8)
+    assert (oid[n:, 0] != gpu.INVALID).sum() > 0
+    sc = gpu.Scene(model, device=0)
+    for mode in (0, 1, 4):
+        sc.set_option("traversal", mode)
+        ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+        assert np.array_equal(ids, oid), f"traversal {mode}: ids"
+        assert np.array_equal(bits(tuv), bits(otuv)), f"traversal {mode}: t,u,v bits"
+        assert np.array_equal(sc.any_hit(o, d).astype(bool), oid[:, 0] != gpu.INVALID), f"traversal {mode}: any hit"
+    sc.close()
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_any_hit_golden(gpu, name):
     g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))

@@ -92,6 +92,56 @@ def test_wide_tree_structure():
     assert reached.all() and inner.sum() == wm.n_nodes - 1
 
 
+def many_meshes_model():
+    """300 small soups and 40 quads (meshes whose tree is one leaf) scattered over a 10 x 10 x 10 box."""
+    from orion_amd import host
+    rng = np.random.default_rng(3)
+    v, i = raygen.triangle_soup(64, edge=0.2, seed=5)
+    parts = []
+    for _ in range(300):
+        vv = v.copy(); vv[:, :3] = vv[:, :3] * 0.3 + rng.uniform(0, 10, 3)
+        parts.append(host.model_from_arrays(vv.astype(np.float32), i))
+    for _ in range(40):
+        q = np.zeros((4, 8), np.float32); c = rng.uniform(0, 10, 3)
+        q[:, 0] = c[0] + np.array([0, .3, .3, 0]); q[:, 1] = c[1]; q[:, 2] = c[2] + np.array([0, 0, .3, .3]); q[:, 4] = 1
+        parts.append(host.model_from_arrays(q, np.array([0, 1, 2, 0, 2, 3], np.uint32)))
+    return host.merge_models(parts)
+
+
+def quad_plane_rays(model, n, seed):
+    """Rays in the planes of the model's leaf-root quads (y = const), at slopes of 10^-7.5 .. 10^-5."""
+    rng = np.random.default_rng(seed)
+    ys = np.array([m.vertices[0, 1] for m in model.meshes if m.n_triangles == 2], np.float64)
+    lo, hi = raygen.scene_bounds(model)
+    p = np.stack([rng.uniform(lo[0], hi[0], n), ys[rng.integers(0, len(ys), n)], rng.uniform(lo[2], hi[2], n)], 1)
+    ang = rng.random(n) * 2 * np.pi
+    d = np.stack([np.cos(ang), 10.0 ** rng.uniform(-7.5, -5, n) * rng.choice([-1, 1], n), np.sin(ang)], 1)
+    o = (p - d * rng.uniform(0.1, 3, n)[:, None]).astype(np.float32)
+    return o, (d * (10.0 ** rng.uniform(-1, 1, n))[:, None]).astype(np.float32)
+
+
+def test_many_meshes_cost_no_more_with_the_guard():
+    """The nodes above the meshes' roots are entered for the rays that meet them (or that a leaf-root mesh forces in),
+    not for every ray: with 340 meshes the guarded walk stays near the unguarded one, and both return the oracle's bits."""
+    model = many_meshes_model()
+    wm = ob.WideModel(model); sc = ob.OracleScene(model)
+    assert wm.h and wm.n_virtual > 100
+    n = 1 << 15
+    o, d = raygen.box_rays(model, n, seed=9)
+    o2, d2 = quad_plane_rays(model, n, seed=10)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    oid, otuv = sc.closest_hit(o, d, threads=8)
+    assert (oid[n:, 0] != 0xFFFFFFFF).sum() > 0
+    per_ray = {}
+    for mode in (PLAIN, GUARDED):
+        ids, tuv, st = wm.closest_hit(o, d, cull=mode, threads=8, kappa=SLACK)
+        assert (ids[:, 0] != ob.WideModel.NOT_TAKEN).all()
+        assert np.array_equal(ids, oid) and np.array_equal(bits(tuv), bits(otuv)), mode
+        # (the cost on the rays across the box; the rays in the quads' planes have all forty quads forced, rightly)
+        per_ray[mode] = wm.closest_hit(o[:n], d[:n], cull=mode, threads=8, kappa=SLACK)[2]["nodes"] / n
+    assert per_ray[GUARDED] < 1.25 * per_ray[PLAIN], per_ray
+
+
 def test_scenes_the_wide_tree_refuses():
     """Trees whose child boxes are not inside their parents' cannot be collapsed (the visit rule would not
     survive): such scenes keep the unculled walk."""

@@ -13,7 +13,7 @@ import conftest  # noqa: E402
 import raygen  # noqa: E402
 from oracle import bindings as ob  # noqa: E402
 
-SLACK = 2.0 ** -7
+SLACK = float(os.environ.get("SLACK_LOG2") and 2.0 ** float(os.environ["SLACK_LOG2"]) or 2.0 ** -7)
 MODES = [int(x) for x in os.environ.get('MODES', '1,2,4').split(',')]
 
 
