@@ -194,6 +194,36 @@ def test_many_meshes_with_leaf_root_quads(gpu):
     sc.close()
 
 
+@pytest.mark.parametrize("kind", ["random", "boxy"])
+def test_random_scenes_agree_in_every_walk(gpu, kind):
+    """A dozen scenes from the fuzzer (tools/ab/fuzz_scenes.py: many meshes, leaf-root quads, degenerate and duplicated
+    triangles; or axis-aligned boxes on a lattice with coincident faces): the oracle, the unculled walk, the default walk
+    and the wide walk return the same bits on rays across the scene, along triangle planes and along the axes."""
+    import sys
+    sys.path.insert(0, os.path.join(conftest.ROOT, "tools", "ab"))
+    import fuzz_scenes as fz
+    from oracle import bindings as ob
+    n = 1 << 14
+    for seed in range(12):
+        model = fz.boxy_model(seed) if kind == "boxy" else fz.random_model(seed)
+        o, d = raygen.box_rays(model, n, seed=seed)
+        o2, d2 = raygen.grazing_rays(model, n, seed=seed + 1)
+        o3, d3 = fz.lattice_rays(model, n, seed=seed + 5)
+        o, d = np.concatenate([o, o2, o3]), np.concatenate([d, d2, d3])
+        oid, otuv = ob.OracleScene(model).closest_hit(o, d, threads=8)
+        sc = gpu.Scene(model, device=0)
+        for mode in (1, 0, 4):
+            try:
+                sc.set_option("traversal", mode)
+            except gpu.OrionError:
+                assert mode == 4
+                continue
+            ids, tuv = hits_to_arrays(sc.closest_hit(o, d))
+            assert np.array_equal(ids, oid), f"{kind} scene {seed}, traversal {mode}: ids"
+            assert np.array_equal(bits(tuv), bits(otuv)), f"{kind} scene {seed}, traversal {mode}: t,u,v bits"
+        sc.close()
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_any_hit_golden(gpu, name):
     g = np.load(os.path.join(conftest.GOLDEN, f"rays_{name}.npz"))
